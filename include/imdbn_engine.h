@@ -1,0 +1,185 @@
+/*
+ * imdbn_engine.h -- C ABI of the MI355X (gfx950) contrastive-divergence engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of francesco-cal98/multimodal-idbn
+ * (SURVEY.md section 8).  The reference has no FFI: the path sits behind Python methods that
+ * dispatch ATen ops.  Each entry point below replaces the ATen sequence of one reference
+ * method (citations: file:line under /root/reference/imdbn/models/).  The Python classes in
+ * multimodal-idbn_amd/imdbn/models/ keep the reference's signatures and call these through
+ * ctypes (cffi, which BASELINE.json names, is not installed in the image).
+ *
+ * Conventions
+ *   - extern "C", no exceptions cross the boundary; every function returns int:
+ *       0 = ok, <0 = IMDBN_E_* below, >0 = hipError_t passed through.
+ *     imdbn_last_error() returns the thread-local message of the last failure.
+ *   - The caller (PyTorch) owns every buffer.  Pointers are raw DEVICE pointers
+ *     (tensor.data_ptr()), fp32 row-major with an explicit leading dimension in ELEMENTS.
+ *     The library allocates nothing persistent; scratch comes from the caller's workspace
+ *     (imdbn_ws_bytes() tells how much; contents need not survive between calls).
+ *   - Every launch goes to the hipStream_t passed in (torch.cuda.current_stream().cuda_stream);
+ *     no call synchronises the host or touches another stream.  Graph-capturable.
+ *   - Parameters are read through the descriptor at EVERY call -- the engine keeps no copy, so
+ *     callers may mutate or re-bind W / biases between calls.
+ *   - Randomness: imdbn_rng says where draws come from, in the reference's draw order
+ *     (SURVEY.md Appendix B).  REPLAY consumes caller-recorded draws (parity tests);
+ *     PHILOX generates Philox-4x32-10 keyed on (seed, draw number, GLOBAL row, column) so
+ *     results do not depend on tiling or on data-parallel sharding.
+ */
+#ifndef IMDBN_ENGINE_H
+#define IMDBN_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMDBN_ABI_VERSION 1
+
+/* error codes (negative) */
+#define IMDBN_E_INVALID   (-1)   /* bad argument (shape, null pointer, alignment) */
+#define IMDBN_E_WORKSPACE (-2)   /* workspace too small */
+#define IMDBN_E_RNG       (-3)   /* replay tape exhausted */
+#define IMDBN_E_NODEVICE  (-4)   /* no gfx950 device */
+#define IMDBN_E_UNSUPPORTED (-5)
+
+/* arithmetic mode of the propagations / association products */
+#define IMDBN_PARITY_F32 0   /* fp32 master weights split hi+mid+lo bf16 in registers: exact products */
+#define IMDBN_FAST_BF16  1   /* one bf16 term per operand (throughput mode; not parity-grade) */
+
+#define IMDBN_RNG_PHILOX 0
+#define IMDBN_RNG_REPLAY 1
+
+#define IMDBN_MAX_GROUPS 4
+
+typedef void* imdbn_stream_t;    /* hipStream_t */
+
+/* One RBM's parameters (rbm.py:41-79).  W is [V][ldw] with ldw >= H. */
+typedef struct imdbn_rbm_desc {
+    float*   W;
+    int64_t  ldw;
+    float*   hid_bias;      /* [H] */
+    float*   vis_bias;      /* [V] */
+    float*   W_m;           /* [V][ldw] momentum buffers; may be NULL for inference-only calls */
+    float*   hb_m;          /* [H] */
+    float*   vb_m;          /* [V] */
+    int32_t  V, H;
+    int32_t  mode;          /* IMDBN_PARITY_F32 | IMDBN_FAST_BF16 */
+    int32_t  n_groups;      /* softmax groups over visible columns (rbm.py:66,113-114) */
+    int32_t  group_start[IMDBN_MAX_GROUPS];
+    int32_t  group_end[IMDBN_MAX_GROUPS];
+} imdbn_rbm_desc;
+
+/* Where random draws come from.  The *_used fields are OUTPUTS: how much the call consumed. */
+typedef struct imdbn_rng {
+    int32_t  mode;          /* IMDBN_RNG_PHILOX | IMDBN_RNG_REPLAY */
+    int32_t  _pad;
+    uint64_t seed;          /* PHILOX key */
+    uint64_t offset;        /* PHILOX: number of the first draw tensor of this call */
+    int64_t  row0;          /* PHILOX: global index of local row 0 (data-parallel shard offset) */
+    const float*   tape;    /* REPLAY: device floats, uniform / normal draw tensors back to back */
+    int64_t        tape_len;
+    const int32_t* cat_tape;/* REPLAY: device int32, one index per (categorical draw, row) */
+    int64_t        cat_len;
+    int64_t  tape_used;     /* out */
+    int64_t  cat_used;      /* out */
+    uint64_t draws_used;    /* out: draw tensors consumed (advance `offset` by this) */
+} imdbn_rng;
+
+/* One half-step pair v -> h -> v' of a conditional chain
+ * (rbm.py:275-291 annealed Gibbs, :337-365 noisy mean-field, :393-399 plain Gibbs). */
+typedef struct imdbn_chain_step {
+    float   T;              /* temperature of both half steps (max(1e-6,T) applied by callee) */
+    float   sigma;          /* std of Gaussian noise added to both logits; 0 = none, no draw */
+    float   eta;            /* mu-pull weight on columns [0,Dz) (rbm.py:359-363); 0 = off */
+    int32_t sample_h;       /* 1: h = 1[p_h > U] ; 0: h = p_h */
+    int32_t vmode;          /* 0: v = p_v ; 1: v = sampleV(p_v) ; 2: v = sampleV(mix(p_v)) w/o re-mix */
+    int32_t clamp;          /* 1: v = v*(1-mask) + v_known*mask (masks must be 0/1) */
+} imdbn_chain_step;
+
+/* Options of one CD update (rbm.py:181-227, :403-483). */
+typedef struct imdbn_cd_opts {
+    int32_t cd_k;           /* Gibbs steps of the negative phase (>=1) */
+    float   lr;             /* effective learning rate: lr/(1+0.01*epoch) [* aux_lr_mult] (rbm.py:194,476) */
+    float   momentum;       /* momentum or final_momentum (rbm.py:195) */
+    float   weight_decay;
+    int32_t sparsity;       /* rbm.py:217-219 (train_epoch only) */
+    float   sparsity_target;
+    int32_t sample_h;       /* clamped step only (rbm.py:462) */
+    int32_t sample_v;       /* clamped step only (rbm.py:468) */
+    int32_t reclamp_negative; /* clamped step only (rbm.py:464) */
+} imdbn_cd_opts;
+
+/* ---- plumbing ------------------------------------------------------------------------- */
+int    imdbn_version(void);
+int    imdbn_last_error(char* buf, size_t n);
+/* cu_count / arch name of the current device; IMDBN_E_NODEVICE without a GPU */
+int    imdbn_device_info(int* cu_count, char* arch, size_t n);
+/* bytes of scratch any call below needs for an RBM of V x H at batch B */
+size_t imdbn_ws_bytes(int V, int H, int B);
+/* tuning knobs (split-K factors); 0 = automatic */
+int    imdbn_set_tuning(int ksplit_up, int ksplit_down);
+/* per-kernel timing of the update kernel with HIP events on the launch stream (bench.py roofline) */
+int    imdbn_profile_enable(int on);
+int    imdbn_profile_read(double* total_ms, int* launches);   /* synchronises the recorded events */
+
+/* ---- K1: p(h|v)   replaces RBM.forward (rbm.py:81-92) ---------------------------------- */
+/* out_prob[B][H] = sigmoid((v W + c)/T);  out_sample (nullable) = 1[out_prob > U] */
+int imdbn_rbm_prop_up(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B, float T,
+                      imdbn_rng* rng, float* out_prob, int64_t ldo, float* out_sample, int64_t lds,
+                      void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+/* ---- K2: p(v|h)   replaces RBM.visible_probs / backward (rbm.py:94-116,137-151) -------- */
+/* out_prob[B][V] = sigmoid((h W^T + b)/T) with softmax over each group; if logits_only: raw logits */
+int imdbn_rbm_prop_down(const imdbn_rbm_desc* d, const float* h, int64_t ldh, int B, float T,
+                        int logits_only, float* out_prob, int64_t ldo,
+                        void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+/* ---- sample_visible (rbm.py:118-135) ---------------------------------------------------- */
+int imdbn_rbm_sample_visible(const imdbn_rbm_desc* d, const float* v_prob, int64_t ldp, int B,
+                             imdbn_rng* rng, float* out, int64_t ldo, imdbn_stream_t stream);
+
+/* ---- one Gibbs step (rbm.py:158-178): outputs v_next, v_prob, h, h_prob ------------------ */
+int imdbn_rbm_gibbs_step(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B,
+                         int sample_h, int sample_v, imdbn_rng* rng,
+                         float* v_next, float* v_prob, float* h, float* h_prob,
+                         void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+/* ---- whole RBM.train_epoch (rbm.py:180-227): K1 -> [K2 -> K1]^k -> K3 -> bias/loss -------- */
+/* loss_out: device float[1] = mean((data - v_prob)^2) */
+int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B,
+                      const imdbn_cd_opts* o, imdbn_rng* rng, float* loss_out,
+                      void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+/* ---- data-parallel split of the same update ------------------------------ */
+/* packed layout (floats): [dW V*H][dc H][db V][sum P+ H][sq-err sum 1][pad to 4] */
+size_t imdbn_packed_delta_floats(int V, int H);
+/* K3a: un-normalised local statistics of rbm.py:199-209 into `packed` (no parameter is touched) */
+int imdbn_rbm_cd_stats(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B,
+                       const imdbn_cd_opts* o, imdbn_rng* rng, float* packed,
+                       void* ws, size_t ws_bytes, imdbn_stream_t stream);
+/* K3b: rbm.py:212-226 from the (all-reduced) packed statistics with n = global batch */
+int imdbn_rbm_apply_delta(const imdbn_rbm_desc* d, const float* packed, int global_B,
+                          const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream);
+
+/* ---- K4: conditional chains (rbm.py:240-400) -------------------------------------------- */
+/* v0 = v_known*mask + (1-mask)*U (init_uniform=1) or v_known (0); then n_steps steps; out_v[B][V].
+ * mu (nullable) is the [B][Dz] pull target of rbm.py:359-363. */
+int imdbn_rbm_chain(const imdbn_rbm_desc* d, const float* v_known, const float* mask, int64_t ldk, int B,
+                    int init_uniform, int n_steps, const imdbn_chain_step* steps,
+                    const float* mu, int64_t ldmu, int Dz, imdbn_rng* rng,
+                    float* out_v, int64_t ldo, void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+/* ---- whole RBM.train_epoch_clamped (rbm.py:402-483) -------------------------------------- */
+/* positive phase = chain(n_init steps) ; negative = cd_k steps from v+ ; update with o->lr */
+int imdbn_rbm_clamped_step(const imdbn_rbm_desc* d, const float* v_known, const float* mask, int64_t ldk, int B,
+                           int n_init, const imdbn_chain_step* init_steps,
+                           const float* mu, int64_t ldmu, int Dz,
+                           const imdbn_cd_opts* o, imdbn_rng* rng, float* loss_out,
+                           void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMDBN_ENGINE_H */

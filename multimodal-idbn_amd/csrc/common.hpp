@@ -1,0 +1,85 @@
+// common.hpp -- device helpers shared by every kernel of the CD engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace imdbn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef uint16_t bf16_t;     // raw bf16 bits in memory
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------
+// Philox-4x32-10.  counter = (column, global row, draw_lo, draw_hi), key = seed.
+// numpy twin: oracle/draws.py:PhiloxStream.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// A source of one logical draw tensor [B][N]: either a replay tape or a Philox draw number.
+struct DrawSrc {
+    const float* tape;   // non-null: replay, element (b,n) at tape[b*N + n]
+    uint64_t seed;
+    uint64_t draw;       // Philox draw number
+    int64_t row0;
+    int N;               // row length of the logical tensor
+};
+
+__device__ __forceinline__ uint4 draw_block(const DrawSrc& s, int b, int n) {
+    const uint64_t row = (uint64_t)(s.row0 + b);
+    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)row, (uint32_t)s.draw, (uint32_t)(s.draw >> 32)),
+                         make_uint2((uint32_t)s.seed, (uint32_t)(s.seed >> 32)));
+}
+
+__device__ __forceinline__ float draw_uniform(const DrawSrc& s, int b, int n) {
+    if (s.tape) return s.tape[(int64_t)b * s.N + n];
+    return (float)(draw_block(s, b, n).x >> 8) * 5.9604644775390625e-08f;   // 2^-24
+}
+
+__device__ __forceinline__ float draw_normal(const DrawSrc& s, int b, int n) {
+    if (s.tape) return s.tape[(int64_t)b * s.N + n];
+    const uint4 x = draw_block(s, b, n);
+    const float u1 = ((float)(x.x >> 8) + 1.0f) * 5.9604644775390625e-08f;
+    const float u2 = (float)(x.y >> 8) * 5.9604644775390625e-08f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 -> bf16 pieces.  split3: x == hi + mid + lo exactly (truncation splits a 24-bit
+// significand into 8+8+8 bits), so three bf16 MFMAs against an exactly-representable operand
+// reproduce the fp32 products.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const uint32_t h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r = x - __uint_as_float(h);
+    const uint32_t m = __float_as_uint(r) & 0xFFFF0000u;
+    const float r2 = r - __uint_as_float(m);
+    hi = h >> 16;
+    mid = m >> 16;
+    lo = __float_as_uint(r2) >> 16;
+}
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// C/D layout of v_mfma_f32_32x32x16_bf16: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace imdbn

@@ -1,0 +1,425 @@
+// kernels_ew.hpp -- element-wise kernels around the MFMA kernels.
+//
+//   finish          split-K slab sum + bias + /T + noise + sigmoid + mu-pull + clamp-mix + Bernoulli
+//                   sampling; emits fp32 outputs, bf16 operand forms, column sums, squared-error partials
+//   finish_groups   softmax groups of the visible layer (rbm.py:113-114,129-133): softmax, categorical
+//   prep_operand    caller fp32 tensor -> bf16 operand forms (+ exactness flag); chain initial state
+//   bias_update     rbm.py:216-226 from the column-sum partials
+//   pack_stats / apply_delta / bias_from_packed   data-parallel split
+//   bernoulli / categorical                       stand-alone sample_visible (rbm.py:118-135)
+//
+// Thread mapping of finish/prep: block = 256 threads = 64 columns x 4 row-quads; a thread owns one
+// column and 8 consecutive batch rows, so fp32 accesses are 256-B row segments per wave and the
+// transposed operand form is one 16-B store per thread.  grid = (ceil(N/64), Bp/32).
+#pragma once
+#include "common.hpp"
+
+namespace imdbn {
+
+struct OperandOut {
+    bf16_t* rm; int64_t rm_ts; int ldrm; int rm_terms;   // row-major   [t][Bp][ldrm]
+    bf16_t* tr; int64_t tr_ts; int tr_terms;             // transposed  [t][N][Bp]
+};
+
+__device__ __forceinline__ uint32_t piece(float x, int t, int terms) {
+    if (terms == 1) return bf16_rne(x);
+    uint32_t p[3];
+    split3(x, p[0], p[1], p[2]);
+    return t == 0 ? p[0] : (t == 1 ? p[1] : p[2]);
+}
+
+// x[i] = value at (row b0+i, col); rows >= B and cols >= N must already be 0.
+__device__ __forceinline__ void store_rm(const OperandOut& o, const float (&x)[8], int b0, int col) {
+    if (o.rm && col < o.ldrm) {
+        for (int t = 0; t < o.rm_terms; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o.rm[t * o.rm_ts + (int64_t)(b0 + i) * o.ldrm + col] = (bf16_t)piece(x[i], t, o.rm_terms);
+    }
+}
+__device__ __forceinline__ void store_tr(const OperandOut& o, const float (&x)[8], int b0, int col, int N, int Bp) {
+    if (o.tr && col < N) {
+        for (int t = 0; t < o.tr_terms; ++t) {
+            uint32_t p[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] = piece(x[i], t, o.tr_terms);
+            *reinterpret_cast<uint4*>(o.tr + t * o.tr_ts + (int64_t)col * Bp + b0) =
+                make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
+        }
+    }
+}
+
+struct FinishArgs {
+    const float* partial; int ks; int64_t slab;    // partial[ks][Bp][N], slab = Bp*N
+    int B, Bp, N;
+    const float* bias; float T;
+    float sigma; DrawSrc noise;
+    int n_groups; int gs[4]; int ge[4];
+    const float* mu; int64_t ldmu; int Dz; float eta;
+    const float* vk; const float* mask; int64_t ldk; int clamp;
+    int vmode; DrawSrc uni;                        // 0 mean-field, 1 sample(p), 2 sample(mix(p)) no re-mix
+    const int32_t* cat_tape; DrawSrc cat_uni;      // categorical source for group g: cat_tape + g*B / draw+g
+    int logits_only;
+    float* out_prob; int64_t ld_prob;
+    float* out_final; int64_t ld_final;
+    OperandOut op; int rm_src, tr_src;             // 0 none, 1 prob, 2 final
+    float* colsum_part; int colsum_src;            // [Bp/32][N]
+    const float* loss_ref; int64_t ld_ref; int loss_src; float* loss_part;   // one per block (+ one per group)
+};
+
+__device__ __forceinline__ bool in_group(const FinishArgs& a, int col) {
+    bool g = false;
+    for (int i = 0; i < a.n_groups; ++i) g |= (col >= a.gs[i] && col < a.ge[i]);
+    return g;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    // fixed-order tree: deterministic
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const float r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void finish(const FinishArgs a) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int b0 = blockIdx.y * 32 + rq * 8;
+    const bool cok = col < a.N;
+    const bool grp = cok && in_group(a, col);
+    const float bias = cok ? a.bias[col] : 0.f;
+    float xp[8], xf[8];
+    float csum = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int b = b0 + i;
+        xp[i] = 0.f; xf[i] = 0.f;
+        if (!cok || b >= a.B) continue;
+        float x = 0.f;
+        const float* pp = a.partial + (int64_t)b * a.N + col;
+        for (int k = 0; k < a.ks; ++k) x += pp[k * a.slab];
+        x = x + bias;
+        if (a.T != 1.0f) x = x / a.T;
+        if (a.sigma > 0.f) x = x + draw_normal(a.noise, b, col) * a.sigma;
+        if (a.logits_only || grp) {                 // group columns: softmax etc. in finish_groups
+            if (a.out_prob) a.out_prob[(int64_t)b * a.ld_prob + col] = x;
+            continue;
+        }
+        float p = sigmoidf_ref(x);
+        if (a.mu && col < a.Dz) p = (1.0f - a.eta) * p + a.eta * a.mu[(int64_t)b * a.ldmu + col];
+        float v;
+        const float m = a.clamp ? a.mask[(int64_t)b * a.ldk + col] : 0.f;
+        const float kn = a.clamp ? a.vk[(int64_t)b * a.ldk + col] : 0.f;
+        if (a.vmode == 0) {
+            v = a.clamp ? (p * (1.0f - m) + kn * m) : p;
+        } else if (a.vmode == 1) {
+            const float s = (p > draw_uniform(a.uni, b, col)) ? 1.f : 0.f;
+            v = a.clamp ? (s * (1.0f - m) + kn * m) : s;
+        } else {
+            const float t = a.clamp ? (p * (1.0f - m) + kn * m) : p;
+            v = (t > draw_uniform(a.uni, b, col)) ? 1.f : 0.f;
+        }
+        if (a.out_prob) a.out_prob[(int64_t)b * a.ld_prob + col] = p;
+        if (a.out_final) a.out_final[(int64_t)b * a.ld_final + col] = v;
+        xp[i] = p; xf[i] = v;
+        csum += (a.colsum_src == 2 ? v : p);
+        if (a.loss_ref) {
+            const float d = a.loss_ref[(int64_t)b * a.ld_ref + col] - (a.loss_src == 2 ? v : p);
+            lsum += d * d;
+        }
+    }
+    if (!a.logits_only) {
+        if (!grp) {   // group columns get their operand forms from finish_groups
+            if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
+            if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
+        }
+    }
+    if (a.colsum_part) {
+        sh[tid] = csum;
+        __syncthreads();
+        if (rq == 0 && cok) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = ((sh[c] + sh[64 + c]) + sh[128 + c]) + sh[192 + c];
+        __syncthreads();
+    }
+    if (a.loss_part) {
+        const float t = block_sum_256(lsum, sh);
+        if (tid == 0) a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// One block (64 threads) per softmax group.  Phase 1: thread = batch row: softmax over the group's
+// logits (left in out_prob by `finish`), mu-pull, clamp-mix, categorical.  Phase 2: thread = column:
+// operand forms, column sums, squared error (sequential over rows: deterministic).
+__global__ __launch_bounds__(64) void finish_groups(const FinishArgs a, int loss_slot0) {
+    __shared__ float sh[64];
+    const int g = blockIdx.x, s = a.gs[g], e = a.ge[g], wd = e - s;
+    const int lane = threadIdx.x;
+    for (int b = lane; b < a.B; b += 64) {
+        float* row = a.out_prob + (int64_t)b * a.ld_prob + s;
+        float mx = -INFINITY;
+        for (int j = 0; j < wd; ++j) mx = fmaxf(mx, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < wd; ++j) sum += expf(row[j] - mx);
+        // categorical over clamp(t,1e-8,1) where t = p (vmode 1) or mix(p) (vmode 2)
+        int idx = -1;
+        float tot = 0.f, thr = 0.f;
+        if (a.vmode != 0) {
+            if (a.cat_tape) idx = a.cat_tape[(int64_t)g * a.B + b];
+            else {
+                DrawSrc cs = a.cat_uni; cs.draw += g; cs.N = 1;
+                thr = draw_uniform(cs, b, 0);
+            }
+        }
+        // first pass: probabilities (and total of the clamped weights for inverse-CDF)
+        for (int j = 0; j < wd; ++j) {
+            const int col = s + j;
+            float p = expf(row[j] - mx) / sum;
+            if (a.mu && col < a.Dz) p = (1.0f - a.eta) * p + a.eta * a.mu[(int64_t)b * a.ldmu + col];
+            row[j] = p;
+            if (a.vmode != 0 && idx < 0) {
+                float t = p;
+                if (a.vmode == 2 && a.clamp) {
+                    const float m = a.mask[(int64_t)b * a.ldk + col];
+                    t = p * (1.0f - m) + a.vk[(int64_t)b * a.ldk + col] * m;
+                }
+                tot += fminf(fmaxf(t, 1e-8f), 1.0f);
+            }
+        }
+        if (a.vmode != 0 && idx < 0) {              // PHILOX: inverse CDF (oracle/draws.py:categorical)
+            const float target = thr * tot;
+            float acc = 0.f;
+            idx = wd - 1;
+            for (int j = 0; j < wd; ++j) {
+                const int col = s + j;
+                float t = row[j];
+                if (a.vmode == 2 && a.clamp) {
+                    const float m = a.mask[(int64_t)b * a.ldk + col];
+                    t = t * (1.0f - m) + a.vk[(int64_t)b * a.ldk + col] * m;
+                }
+                acc += fminf(fmaxf(t, 1e-8f), 1.0f);
+                if (acc > target) { idx = j; break; }
+            }
+        }
+        if (a.out_final) {
+            for (int j = 0; j < wd; ++j) {
+                const int col = s + j;
+                const float p = row[j];
+                const float m = a.clamp ? a.mask[(int64_t)b * a.ldk + col] : 0.f;
+                const float kn = a.clamp ? a.vk[(int64_t)b * a.ldk + col] : 0.f;
+                float v;
+                if (a.vmode == 0) v = a.clamp ? (p * (1.0f - m) + kn * m) : p;
+                else if (a.vmode == 1) { const float o = (j == idx) ? 1.f : 0.f; v = a.clamp ? (o * (1.0f - m) + kn * m) : o; }
+                else v = (j == idx) ? 1.f : 0.f;
+                a.out_final[(int64_t)b * a.ld_final + col] = v;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    float lsum = 0.f;
+    for (int j = lane; j < wd; j += 64) {
+        const int col = s + j;
+        float csum = 0.f;
+        for (int b0 = 0; b0 < a.Bp; b0 += 8) {
+            float xp[8], xf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int b = b0 + i;
+                const bool ok = b < a.B;
+                xp[i] = ok ? a.out_prob[(int64_t)b * a.ld_prob + col] : 0.f;
+                xf[i] = (ok && a.out_final) ? a.out_final[(int64_t)b * a.ld_final + col] : 0.f;
+                if (ok) {
+                    csum += (a.colsum_src == 2 ? xf[i] : xp[i]);
+                    if (a.loss_ref) {
+                        const float d = a.loss_ref[(int64_t)b * a.ld_ref + col] - (a.loss_src == 2 ? xf[i] : xp[i]);
+                        lsum += d * d;
+                    }
+                }
+            }
+            if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
+            if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
+        }
+        if (a.colsum_part) {
+            const int P = a.Bp / 32;
+            a.colsum_part[col] = csum;
+            for (int p = 1; p < P; ++p) a.colsum_part[(int64_t)p * a.N + col] = 0.f;
+        }
+    }
+    if (a.loss_part) {
+        sh[lane] = lsum;
+        __syncthreads();
+        if (lane == 0) {
+            float t = 0.f;
+            for (int i = 0; i < 64; ++i) t += sh[i];
+            a.loss_part[loss_slot0 + g] = t;
+        }
+    }
+}
+
+// Caller tensor -> operand forms.  With `mix`: x = vk*m + (1-m)*U  (chain initial state,
+// rbm.py:271,333,392) and the mixed tensor is also written to out_f32.
+struct PrepArgs {
+    const float* in; int64_t ld; int B, Bp, N;
+    int mix; const float* mask; int64_t ldm; DrawSrc uni;
+    float* out_f32; int64_t ldo;
+    OperandOut op; int* flag;      // flag |= 1 if any element is not exactly one bf16 term
+};
+
+__global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
+    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int b0 = blockIdx.y * 32 + rq * 8;
+    float x[8];
+    bool inexact = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int b = b0 + i;
+        x[i] = 0.f;
+        if (col < a.N && b < a.B) {
+            float v = a.in[(int64_t)b * a.ld + col];
+            if (a.mix) {
+                const float m = a.mask[(int64_t)b * a.ldm + col];
+                v = v * m + (1.0f - m) * draw_uniform(a.uni, b, col);
+            }
+            if (a.out_f32) a.out_f32[(int64_t)b * a.ldo + col] = v;
+            x[i] = v;
+            inexact |= (__float_as_uint(v) & 0xFFFFu) != 0u;
+        }
+    }
+    if (a.flag && inexact) atomicOr(a.flag, 1);
+    store_rm(a.op, x, b0, col);
+    store_tr(a.op, x, b0, col, a.N, a.Bp);
+}
+
+// rbm.py:216-226.  parts are [P][len] column-sum partials; loss parts are summed in double.
+struct BiasArgs {
+    float* hid_bias; float* hb_m; int H; const float* hpos; const float* hneg;
+    float* vis_bias; float* vb_m; int V; const float* vpos; const float* vneg;
+    int P; float lr, mom, n; int sparsity; float target;
+    const float* loss_part; int n_loss; float loss_den; float* loss_out;
+};
+
+__device__ __forceinline__ float sum_parts(const float* p, int P, int len, int i) {
+    float s = 0.f;
+    for (int k = 0; k < P; ++k) s += p[(int64_t)k * len + i];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void bias_update(const BiasArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.H) {
+        const float sp = sum_parts(a.hpos, a.P, a.H, i), sn = sum_parts(a.hneg, a.P, a.H, i);
+        float m = a.hb_m[i] * a.mom;
+        m = m + (a.lr * (sp - sn)) / a.n;                                   // rbm.py:216
+        if (a.sparsity) m = m + (-a.lr) * (sp / a.n - a.target);           // rbm.py:218-219
+        a.hb_m[i] = m;
+        a.hid_bias[i] += m;
+    }
+    if (i < a.V) {
+        const float sp = sum_parts(a.vpos, a.P, a.V, i), sn = sum_parts(a.vneg, a.P, a.V, i);
+        float m = a.vb_m[i] * a.mom;
+        m = m + (a.lr * (sp - sn)) / a.n;                                   // rbm.py:223
+        a.vb_m[i] = m;
+        a.vis_bias[i] += m;
+    }
+    if (i == 0 && a.loss_out) {
+        double t = 0.0;
+        for (int k = 0; k < a.n_loss; ++k) t += (double)a.loss_part[k];
+        a.loss_out[0] = (float)(t / (double)a.loss_den);                    // rbm.py:226
+    }
+}
+
+// ---- data-parallel split ------------------------------------------------------------------
+// packed = [dW V*H][dc H][db V][sumP+ H][sqerr 1][pad]
+struct PackArgs {
+    float* tail; int H, V; const float* hpos; const float* hneg; const float* vpos; const float* vneg; int P;
+    const float* loss_part; int n_loss;
+};
+__global__ __launch_bounds__(256) void pack_stats(const PackArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.H) {
+        const float sp = sum_parts(a.hpos, a.P, a.H, i), sn = sum_parts(a.hneg, a.P, a.H, i);
+        a.tail[i] = sp - sn;
+        a.tail[a.H + a.V + i] = sp;
+    }
+    if (i < a.V) a.tail[a.H + i] = sum_parts(a.vpos, a.P, a.V, i) - sum_parts(a.vneg, a.P, a.V, i);
+    if (i == 0) {
+        double t = 0.0;
+        for (int k = 0; k < a.n_loss; ++k) t += (double)a.loss_part[k];
+        a.tail[2 * a.H + a.V] = (float)t;
+    }
+}
+
+struct ApplyArgs {
+    float* W; float* Wm; int64_t ldw; int V, H; const float* packed;
+    float* hid_bias; float* hb_m; float* vis_bias; float* vb_m;
+    float lr, mom, wd, n; int sparsity; float target; float* loss_out;
+};
+__global__ __launch_bounds__(256) void apply_delta(const ApplyArgs a) {
+    const int64_t total = (int64_t)a.V * a.H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / a.H, col = i - row * a.H;
+        const int64_t idx = row * a.ldw + col;
+        const float wold = a.W[idx];
+        float m = a.Wm[idx] * a.mom;
+        m = m + a.lr * (a.packed[i] / a.n - a.wd * wold);
+        a.Wm[idx] = m;
+        a.W[idx] = wold + m;
+    }
+    const float* tail = a.packed + total;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 < (unsigned)max(a.V, a.H)) {
+        if (i < a.H) {
+            float m = a.hb_m[i] * a.mom;
+            m = m + (a.lr * tail[i]) / a.n;
+            if (a.sparsity) m = m + (-a.lr) * (tail[a.H + a.V + i] / a.n - a.target);
+            a.hb_m[i] = m;
+            a.hid_bias[i] += m;
+        }
+        if (i < a.V) {
+            float m = a.vb_m[i] * a.mom;
+            m = m + (a.lr * tail[a.H + i]) / a.n;
+            a.vb_m[i] = m;
+            a.vis_bias[i] += m;
+        }
+        if (i == 0 && a.loss_out) a.loss_out[0] = tail[2 * a.H + a.V] / (a.n * (float)a.V);
+    }
+}
+
+// ---- stand-alone sample_visible (rbm.py:125-135) -------------------------------------------
+__global__ __launch_bounds__(256) void bernoulli_rows(const float* p, int64_t ldp, int B, int N, DrawSrc uni, float* out, int64_t ldo) {
+    const int64_t total = (int64_t)B * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / N), n = (int)(i - (int64_t)b * N);
+        out[(int64_t)b * ldo + n] = (p[(int64_t)b * ldp + n] > draw_uniform(uni, b, n)) ? 1.f : 0.f;
+    }
+}
+__global__ __launch_bounds__(64) void categorical_rows(const float* p, int64_t ldp, int B, int s, int e,
+                                                       const int32_t* cat_tape, DrawSrc cu, float* out, int64_t ldo) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int wd = e - s;
+    int idx;
+    if (cat_tape) idx = cat_tape[b];
+    else {
+        float tot = 0.f;
+        for (int j = 0; j < wd; ++j) tot += fminf(fmaxf(p[(int64_t)b * ldp + s + j], 1e-8f), 1.0f);
+        cu.N = 1;
+        const float target = draw_uniform(cu, b, 0) * tot;
+        float acc = 0.f;
+        idx = wd - 1;
+        for (int j = 0; j < wd; ++j) {
+            acc += fminf(fmaxf(p[(int64_t)b * ldp + s + j], 1e-8f), 1.0f);
+            if (acc > target) { idx = j; break; }
+        }
+    }
+    for (int j = 0; j < wd; ++j) out[(int64_t)b * ldo + s + j] = (j == idx) ? 1.f : 0.f;
+}
+
+}  // namespace imdbn

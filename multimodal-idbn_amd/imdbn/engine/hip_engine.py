@@ -1,0 +1,294 @@
+"""HipEngine: torch tensors in, C-ABI calls out.  The only thing between ``RBM`` methods and the HIP kernels.
+
+PyTorch is plumbing here (device memory, current stream); every arithmetic step of the hot path
+runs in ``libimdbn_hip.so``.  Parameters are read from the RBM object at EVERY call (callers may
+mutate or re-bind ``W``/biases behind the RBM's back); the engine holds only
+scratch workspaces keyed on (device, V, H, B).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import native as N
+from . import rng as R
+
+
+def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.size(1):
+        return t
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class HipEngine:
+    name = "hip"
+
+    def __init__(self):
+        self._lib = N.lib()
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self.mode = N.PARITY_F32
+
+    # ---- plumbing -----------------------------------------------------------------------------
+    def device_info(self):
+        cu = C.c_int(0)
+        buf = C.create_string_buffer(64)
+        N.check(self._lib.imdbn_device_info(C.byref(cu), buf, 64), "imdbn_device_info")
+        return cu.value, buf.value.decode()
+
+    def set_tuning(self, ksplit_up: int = 0, ksplit_down: int = 0):
+        N.check(self._lib.imdbn_set_tuning(int(ksplit_up), int(ksplit_down)), "imdbn_set_tuning")
+        self._ws.clear()
+
+    def profile(self, on: bool):
+        N.check(self._lib.imdbn_profile_enable(1 if on else 0), "imdbn_profile_enable")
+
+    def profile_read(self) -> Tuple[float, int]:
+        ms, n = C.c_double(0), C.c_int(0)
+        N.check(self._lib.imdbn_profile_read(C.byref(ms), C.byref(n)), "imdbn_profile_read")
+        return ms.value, n.value
+
+    def _workspace(self, dev, V, H, B):
+        key = (dev, V, H, B)
+        ws = self._ws.get(key)
+        need = int(self._lib.imdbn_ws_bytes(V, H, B))
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    @staticmethod
+    def _stream(dev):
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def _desc(self, rbm, need_momentum: bool) -> N.RbmDesc:
+        W = rbm.W.data
+        if not W.is_cuda:
+            raise N.EngineError("HipEngine needs CUDA/HIP tensors (RBM.W is on %s)" % W.device)
+        if W.dtype != torch.float32 or W.dim() != 2 or W.stride(1) != 1:
+            raise N.EngineError("RBM.W must be fp32 [V,H] with unit inner stride")
+        V, H = W.shape
+        d = N.RbmDesc()
+        d.W, d.ldw, d.V, d.H = W.data_ptr(), W.stride(0), V, H
+        hb, vb = rbm.hid_bias.data, rbm.vis_bias.data
+        for t, n, nm in ((hb, H, "hid_bias"), (vb, V, "vis_bias")):
+            if t.device != W.device or t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+                raise N.EngineError(f"RBM.{nm} must be contiguous fp32 [{n}] on {W.device}")
+        d.hid_bias, d.vis_bias = hb.data_ptr(), vb.data_ptr()
+        if need_momentum:
+            # momentum buffers are plain attributes, not moved by .to() (rbm.py:77-79): re-home them
+            for nm, ref in (("W_m", W), ("hb_m", hb), ("vb_m", vb)):
+                m = getattr(rbm, nm, None)
+                if m is None or m.shape != ref.shape:
+                    m = torch.zeros_like(ref)
+                elif m.device != ref.device or m.dtype != torch.float32 or not m.is_contiguous():
+                    m = m.to(device=ref.device, dtype=torch.float32).contiguous()
+                setattr(rbm, nm, m)
+            if rbm.W_m.stride(0) != W.stride(0):
+                raise N.EngineError("W_m must share W's row stride")
+            d.W_m, d.hb_m, d.vb_m = rbm.W_m.data_ptr(), rbm.hb_m.data_ptr(), rbm.vb_m.data_ptr()
+        groups = list(getattr(rbm, "softmax_groups", None) or [])
+        if len(groups) > N.MAX_GROUPS:
+            raise N.EngineError(f"at most {N.MAX_GROUPS} softmax groups supported")
+        d.n_groups = len(groups)
+        for i, (s, e) in enumerate(groups):
+            d.group_start[i], d.group_end[i] = int(s), int(e)
+        d.mode = self.mode
+        return d
+
+    @staticmethod
+    def _groups(rbm):
+        return [(int(s), int(e)) for s, e in (getattr(rbm, "softmax_groups", None) or [])]
+
+    def _rng(self, rng, schedule: R.Schedule, B: int, dev):
+        """native rng struct + keep-alive tensors"""
+        r = N.Rng()
+        keep = None
+        if isinstance(rng, R.ReplayRng):
+            ft, ct = rng.build(schedule, B, dev)
+            r.mode = N.RNG_REPLAY
+            r.tape, r.tape_len = ft.data_ptr(), ft.numel()
+            r.cat_tape, r.cat_len = ct.data_ptr(), ct.numel()
+            keep = (ft, ct)
+        elif isinstance(rng, R.PhiloxRng):
+            r.mode = N.RNG_PHILOX
+            r.seed, r.offset, r.row0 = rng.seed, rng.offset, rng.row0
+        else:
+            raise N.EngineError("rng must be PhiloxRng or ReplayRng")
+        return r, keep
+
+    @staticmethod
+    def _done(rng, r: N.Rng, schedule):
+        if r.draws_used != len(schedule):
+            raise N.EngineError(f"draw schedule mismatch: engine consumed {r.draws_used}, host planned {len(schedule)}")
+        rng.advance(r.draws_used)
+
+    def skip_draws(self, rng, schedule: R.Schedule, B: int):
+        """Consume draws without computing (dead refinement passes of _cross_reconstruct)."""
+        if isinstance(rng, R.ReplayRng):
+            rng.build(schedule, B, "cpu")
+        else:
+            rng.advance(len(schedule))
+
+    @staticmethod
+    def _steps(steps: Sequence[dict]):
+        arr = (N.ChainStep * max(1, len(steps)))()
+        for i, s in enumerate(steps):
+            arr[i].T, arr[i].sigma, arr[i].eta = float(s["T"]), float(s["sigma"]), float(s["eta"])
+            arr[i].sample_h, arr[i].vmode, arr[i].clamp = int(s["sample_h"]), int(s["vmode"]), int(s["clamp"])
+        return arr
+
+    # ---- propagations -------------------------------------------------------------------------
+    def prop_up(self, rbm, v, T=1.0, sample=False, rng=None):
+        d = self._desc(rbm, False)
+        v = _f32c(v, "v")
+        B, dev = v.size(0), v.device
+        out = torch.empty(B, d.H, device=dev)
+        smp = torch.empty(B, d.H, device=dev) if sample else None
+        sched = [("u", d.H)] if sample else []
+        r, keep = self._rng(rng, sched, B, dev) if sample else (None, None)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_prop_up(C.byref(d), _ptr(v), v.stride(0), B, float(T), C.byref(r) if r else None,
+                                             _ptr(out), out.stride(0), _ptr(smp), d.H, _ptr(ws), ws.numel(),
+                                             self._stream(dev)), "imdbn_rbm_prop_up")
+        if sample:
+            self._done(rng, r, sched)
+            return out, smp
+        return out
+
+    def prop_down(self, rbm, h, T=1.0, logits_only=False):
+        d = self._desc(rbm, False)
+        h = _f32c(h, "h")
+        B, dev = h.size(0), h.device
+        out = torch.empty(B, d.V, device=dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_prop_down(C.byref(d), _ptr(h), h.stride(0), B, float(T), 1 if logits_only else 0,
+                                               _ptr(out), out.stride(0), _ptr(ws), ws.numel(), self._stream(dev)),
+                "imdbn_rbm_prop_down")
+        return out
+
+    def sample_visible(self, rbm, v_prob, rng):
+        d = self._desc(rbm, False)
+        p = _f32c(v_prob, "v_prob")
+        B, dev = p.size(0), p.device
+        out = torch.empty(B, d.V, device=dev)
+        sched = R.sched_sample_visible(d.V, self._groups(rbm))
+        r, keep = self._rng(rng, sched, B, dev)
+        N.check(self._lib.imdbn_rbm_sample_visible(C.byref(d), _ptr(p), p.stride(0), B, C.byref(r), _ptr(out),
+                                                    out.stride(0), self._stream(dev)), "imdbn_rbm_sample_visible")
+        self._done(rng, r, sched)
+        return out
+
+    def gibbs_step(self, rbm, v, sample_h, sample_v, rng):
+        d = self._desc(rbm, False)
+        v = _f32c(v, "v")
+        B, dev = v.size(0), v.device
+        v_next, v_prob = torch.empty(B, d.V, device=dev), torch.empty(B, d.V, device=dev)
+        h, h_prob = torch.empty(B, d.H, device=dev), torch.empty(B, d.H, device=dev)
+        sched = ([("u", d.H)] if sample_h else []) + (R.sched_sample_visible(d.V, self._groups(rbm)) if sample_v else [])
+        r, keep = self._rng(rng, sched, B, dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_gibbs_step(C.byref(d), _ptr(v), v.stride(0), B, int(bool(sample_h)), int(bool(sample_v)),
+                                                C.byref(r), _ptr(v_next), _ptr(v_prob), _ptr(h), _ptr(h_prob),
+                                                _ptr(ws), ws.numel(), self._stream(dev)), "imdbn_rbm_gibbs_step")
+        self._done(rng, r, sched)
+        return v_next, v_prob, h, h_prob
+
+    # ---- CD updates ---------------------------------------------------------------------------
+    @staticmethod
+    def _opts(rbm, lr, mom, cd_k, sparsity=False, sample_h=False, sample_v=False, reclamp=True) -> N.CdOpts:
+        o = N.CdOpts()
+        o.cd_k, o.lr, o.momentum, o.weight_decay = int(cd_k), float(lr), float(mom), float(rbm.weight_decay)
+        o.sparsity, o.sparsity_target = int(bool(sparsity)), float(getattr(rbm, "sparsity_factor", 0.0))
+        o.sample_h, o.sample_v, o.reclamp_negative = int(bool(sample_h)), int(bool(sample_v)), int(bool(reclamp))
+        return o
+
+    def cd_step(self, rbm, data, lr, mom, cd_k, rng):
+        d = self._desc(rbm, True)
+        x = _f32c(data, "data")
+        B, dev = x.size(0), x.device
+        o = self._opts(rbm, lr, mom, cd_k, sparsity=getattr(rbm, "sparsity", False))
+        sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
+        r, keep = self._rng(rng, sched, B, dev)
+        loss = torch.empty(1, device=dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_cd_step(C.byref(d), _ptr(x), x.stride(0), B, C.byref(o), C.byref(r), _ptr(loss),
+                                             _ptr(ws), ws.numel(), self._stream(dev)), "imdbn_rbm_cd_step")
+        self._done(rng, r, sched)
+        return loss.reshape(())
+
+    def packed_floats(self, V, H) -> int:
+        return int(self._lib.imdbn_packed_delta_floats(V, H))
+
+    def cd_stats(self, rbm, data, cd_k, rng, out: Optional[torch.Tensor] = None):
+        d = self._desc(rbm, False)
+        x = _f32c(data, "data")
+        B, dev = x.size(0), x.device
+        o = self._opts(rbm, 0.0, 0.0, cd_k)
+        sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
+        r, keep = self._rng(rng, sched, B, dev)
+        n = self.packed_floats(d.V, d.H)
+        packed = out if out is not None else torch.zeros(n, device=dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_cd_stats(C.byref(d), _ptr(x), x.stride(0), B, C.byref(o), C.byref(r), _ptr(packed),
+                                              _ptr(ws), ws.numel(), self._stream(dev)), "imdbn_rbm_cd_stats")
+        self._done(rng, r, sched)
+        return packed
+
+    def apply_delta(self, rbm, packed, global_B, lr, mom):
+        d = self._desc(rbm, True)
+        dev = packed.device
+        o = self._opts(rbm, lr, mom, 1, sparsity=getattr(rbm, "sparsity", False))
+        loss = torch.empty(1, device=dev)
+        N.check(self._lib.imdbn_rbm_apply_delta(C.byref(d), _ptr(packed), int(global_B), C.byref(o), _ptr(loss),
+                                                 self._stream(dev)), "imdbn_rbm_apply_delta")
+        return loss.reshape(())
+
+    # ---- chains -------------------------------------------------------------------------------
+    def chain(self, rbm, v_known, mask, steps: List[dict], rng, init_uniform=True, mu=None):
+        d = self._desc(rbm, False)
+        vk, km = _f32c(v_known, "v_known"), _f32c(mask, "mask")
+        if vk.stride(0) != km.stride(0):
+            vk, km = vk.contiguous(), km.contiguous()
+        B, dev = vk.size(0), vk.device
+        out = torch.empty(B, d.V, device=dev)
+        sched = R.sched_chain(d.V, d.H, self._groups(rbm), steps, init_uniform)
+        r, keep = self._rng(rng, sched, B, dev)
+        mu_t = _f32c(mu, "mu") if mu is not None else None
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_chain(C.byref(d), _ptr(vk), _ptr(km), vk.stride(0), B, int(bool(init_uniform)), len(steps),
+                                           self._steps(steps), _ptr(mu_t), mu_t.stride(0) if mu_t is not None else 0,
+                                           mu_t.size(1) if mu_t is not None else 0, C.byref(r), _ptr(out), out.stride(0),
+                                           _ptr(ws), ws.numel(), self._stream(dev)), "imdbn_rbm_chain")
+        self._done(rng, r, sched)
+        return out
+
+    def clamped_step(self, rbm, v_known, mask, init_steps: List[dict], mu, lr, mom, cd_k, sample_h, sample_v, reclamp, rng):
+        d = self._desc(rbm, True)
+        vk, km = _f32c(v_known, "v_known"), _f32c(mask, "mask")
+        if vk.stride(0) != km.stride(0):
+            vk, km = vk.contiguous(), km.contiguous()
+        B, dev = vk.size(0), vk.device
+        o = self._opts(rbm, lr, mom, cd_k, sparsity=False, sample_h=sample_h, sample_v=sample_v, reclamp=reclamp)
+        sched = R.sched_clamped(d.V, d.H, self._groups(rbm), init_steps, cd_k, sample_h, sample_v)
+        r, keep = self._rng(rng, sched, B, dev)
+        mu_t = _f32c(mu, "mu") if mu is not None else None
+        loss = torch.empty(1, device=dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_clamped_step(C.byref(d), _ptr(vk), _ptr(km), vk.stride(0), B, len(init_steps),
+                                                  self._steps(init_steps), _ptr(mu_t),
+                                                  mu_t.stride(0) if mu_t is not None else 0,
+                                                  mu_t.size(1) if mu_t is not None else 0, C.byref(o), C.byref(r),
+                                                  _ptr(loss), _ptr(ws), ws.numel(), self._stream(dev)),
+                "imdbn_rbm_clamped_step")
+        self._done(rng, r, sched)
+        return loss.reshape(())

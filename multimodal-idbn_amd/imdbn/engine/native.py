@@ -1,0 +1,108 @@
+"""ctypes binding of the C ABI in ``include/imdbn_engine.h`` (one-to-one; no logic here).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` into
+``multimodal-idbn_amd/lib/libimdbn_hip.so``.  There is NO CPU fallback: if the library is
+missing or fails to load, :func:`lib` raises and every engine call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_GROUPS = 4
+PARITY_F32, FAST_BF16 = 0, 1
+RNG_PHILOX, RNG_REPLAY = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libimdbn_hip.so"))
+
+
+class RbmDesc(C.Structure):
+    _fields_ = [
+        ("W", C.c_void_p), ("ldw", C.c_int64),
+        ("hid_bias", C.c_void_p), ("vis_bias", C.c_void_p),
+        ("W_m", C.c_void_p), ("hb_m", C.c_void_p), ("vb_m", C.c_void_p),
+        ("V", C.c_int32), ("H", C.c_int32), ("mode", C.c_int32), ("n_groups", C.c_int32),
+        ("group_start", C.c_int32 * MAX_GROUPS), ("group_end", C.c_int32 * MAX_GROUPS),
+    ]
+
+
+class Rng(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("_pad", C.c_int32),
+        ("seed", C.c_uint64), ("offset", C.c_uint64), ("row0", C.c_int64),
+        ("tape", C.c_void_p), ("tape_len", C.c_int64),
+        ("cat_tape", C.c_void_p), ("cat_len", C.c_int64),
+        ("tape_used", C.c_int64), ("cat_used", C.c_int64), ("draws_used", C.c_uint64),
+    ]
+
+
+class ChainStep(C.Structure):
+    _fields_ = [("T", C.c_float), ("sigma", C.c_float), ("eta", C.c_float),
+                ("sample_h", C.c_int32), ("vmode", C.c_int32), ("clamp", C.c_int32)]
+
+
+class CdOpts(C.Structure):
+    _fields_ = [("cd_k", C.c_int32), ("lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float),
+                ("sparsity", C.c_int32), ("sparsity_target", C.c_float),
+                ("sample_h", C.c_int32), ("sample_v", C.c_int32), ("reclamp_negative", C.c_int32)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_INT = C.c_int
+_F = C.c_float
+_SZ = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol the header declares
+SIGNATURES = {
+    "imdbn_version": (_INT, []),
+    "imdbn_last_error": (_INT, [C.c_char_p, _SZ]),
+    "imdbn_device_info": (_INT, [C.POINTER(_INT), C.c_char_p, _SZ]),
+    "imdbn_ws_bytes": (_SZ, [_INT, _INT, _INT]),
+    "imdbn_set_tuning": (_INT, [_INT, _INT]),
+    "imdbn_profile_enable": (_INT, [_INT]),
+    "imdbn_profile_read": (_INT, [C.POINTER(C.c_double), C.POINTER(_INT)]),
+    "imdbn_rbm_prop_up": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _F, C.POINTER(Rng), _P, _I64, _P, _I64, _P, _SZ, _P]),
+    "imdbn_rbm_prop_down": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _F, _INT, _P, _I64, _P, _SZ, _P]),
+    "imdbn_rbm_sample_visible": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(Rng), _P, _I64, _P]),
+    "imdbn_rbm_gibbs_step": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _INT, _INT, C.POINTER(Rng), _P, _P, _P, _P, _P, _SZ, _P]),
+    "imdbn_rbm_cd_step": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
+    "imdbn_packed_delta_floats": (_SZ, [_INT, _INT]),
+    "imdbn_rbm_cd_stats": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
+    "imdbn_rbm_apply_delta": (_INT, [C.POINTER(RbmDesc), _P, _INT, C.POINTER(CdOpts), _P, _P]),
+    "imdbn_rbm_chain": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
+                               C.POINTER(Rng), _P, _I64, _P, _SZ, _P]),
+    "imdbn_rbm_clamped_step": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
+                                      C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the native library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f"native HIP engine not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` at the repo root. There is no CPU fallback for this path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        buf = C.create_string_buffer(512)
+        lib().imdbn_last_error(buf, 512)
+        raise EngineError(f"{what} failed (rc={rc}): {buf.value.decode(errors='replace')}")

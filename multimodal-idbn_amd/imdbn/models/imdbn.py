@@ -1,0 +1,363 @@
+"""iMDBN: image iDBN + joint RBM over [z_img, y_onehot], backed by the MI355X CD engine.
+
+Mirror of the reference ``imdbn/models/imdbn.py`` for the hot path (a15-a21):
+constructor / ``_build_joint`` (:68-214), ``init_joint_bias_from_data`` (:216-292),
+``load_pretrained_image_idbn`` (:294-342), ``finetune_image_last_layer`` (:344-384),
+``_cross_reconstruct`` (:386-488), ``represent`` (:490-506), the ``train_joint`` batch loop with its
+online metrics (:553-639), ``save_model`` / ``load_model`` (:815-934).  The wandb / PCA / probe /
+snapshot tail (:641-813) is the observability side-car and is out of scope.
+
+All RBM arithmetic goes through the engine; the few torch ops left here (concatenation, class-mean
+bookkeeping, argmax/top-k of the online metrics) are host-logic plumbing on small tensors.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+import pickle
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from imdbn import engine as _E
+from imdbn.models.idbn import iDBN
+from imdbn.models.rbm import RBM
+
+WARMUP_Y_EPOCHS = 8          # imdbn.py:540
+Z_CLAMP_EVERY = 50           # imdbn.py:600
+KBUF = 5                     # imdbn.py:452
+
+
+class iMDBN(nn.Module):
+    def __init__(
+        self,
+        layer_sizes_img: list,
+        layer_sizes_txt_or_joint=None,
+        joint_layer_size: Optional[int] = None,
+        params: Optional[dict] = None,
+        dataloader=None,
+        val_loader=None,
+        device=None,
+        text_posenc_dim: int = 0,
+        num_labels: int = 32,
+        embedding_dim: int = 64,
+        wandb_run=None,
+        logging_config_path: Optional[str] = None,
+        logging_cfg: Optional[dict] = None,
+    ):
+        super().__init__()
+        # two accepted signatures (imdbn.py:105-112): (img_layers, txt_layers, joint) or (img_layers, joint)
+        if isinstance(layer_sizes_txt_or_joint, (list, tuple)):
+            if joint_layer_size is None:
+                raise ValueError("joint_layer_size required with legacy constructor signature")
+        elif joint_layer_size is None:
+            joint_layer_size = int(layer_sizes_txt_or_joint)
+
+        self.params = params or {}
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.dataloader = dataloader
+        self.val_loader = val_loader
+        self.wandb_run = wandb_run
+        self.logging_cfg = logging_cfg if logging_cfg is not None else {}
+        self.num_labels = int(num_labels)
+
+        try:                                                                        # imdbn.py:137-145
+            vb_imgs, vb_lbls = next(iter(val_loader))
+            self.validation_images = vb_imgs[:8].to(self.device)
+            self.validation_labels = vb_lbls[:8].to(self.device)
+            self.val_batch = (vb_imgs, vb_lbls)
+        except Exception:
+            self.validation_images = None
+            self.validation_labels = None
+            self.val_batch = None
+
+        self.image_idbn = iDBN(
+            layer_sizes=layer_sizes_img, params=self.params, dataloader=self.dataloader,
+            val_loader=self.val_loader, device=self.device, wandb_run=self.wandb_run,
+            logging_config_path=logging_config_path,
+        )
+        self.Dz_img = int(self.image_idbn.layers[-1].num_hidden)
+        self._build_joint(Dz_img=self.Dz_img, joint_hidden=joint_layer_size)
+
+        self.joint_cd = int(self.params.get("JOINT_CD", self.params.get("CD", 1)))  # imdbn.py:164-167
+        self.cross_steps = int(self.params.get("CROSS_GIBBS_STEPS", 50))
+        self.aux_every_k = int(self.params.get("JOINT_AUX_EVERY_K", 0))
+        self.aux_cond_steps = int(self.params.get("JOINT_AUX_COND_STEPS", 50))
+        self.features = None
+        self.arch_str = f"IMG{'-'.join(map(str, layer_sizes_img))}_JOINT{joint_layer_size}"
+
+    def _build_joint(self, Dz_img: int, joint_hidden: int):
+        """imdbn.py:203-214: visible = [z_img (Dz) | y (K, one softmax group)]."""
+        self.Dz_img = int(Dz_img)
+        K = self.num_labels
+        p = self.params
+        self.joint_rbm = RBM(
+            num_visible=self.Dz_img + K,
+            num_hidden=int(joint_hidden),
+            learning_rate=p.get("JOINT_LEARNING_RATE", p.get("LEARNING_RATE", 0.1)),
+            weight_decay=p.get("WEIGHT_PENALTY", 0.0001),
+            momentum=p.get("INIT_MOMENTUM", 0.5),
+            dynamic_lr=p.get("LEARNING_RATE_DYNAMIC", True),
+            final_momentum=p.get("FINAL_MOMENTUM", 0.95),
+            softmax_groups=[(self.Dz_img, self.Dz_img + K)],
+        ).to(self.device)
+
+    # ---- bias initialisation (imdbn.py:216-292) ---------------------------------------------------
+    @torch.no_grad()
+    def init_joint_bias_from_data(self, n_batches: int = 10):
+        if not hasattr(self, "Dz_img"):
+            self.Dz_img = int(self.joint_rbm.num_visible) - self.num_labels
+        Dz, K = self.Dz_img, self.num_labels
+        sum_z, n = None, 0
+        class_counts = torch.zeros(K, device=self.device)
+        zs, ys = [], []
+        for b, (imgs, lbls) in enumerate(self.dataloader):
+            if b >= n_batches:
+                break
+            z = self.image_idbn.represent(imgs.to(self.device).view(imgs.size(0), -1).float())
+            sum_z = z.sum(0) if sum_z is None else (sum_z + z.sum(0))
+            n += z.size(0)
+            class_counts += lbls.to(self.device).float().sum(0)
+            zs.append(z)
+            ys.append(lbls.to(self.device).argmax(dim=1))
+        if n == 0:
+            return
+        mean_z = (sum_z / n).clamp(1e-4, 1 - 1e-4)                                  # :256
+        priors = class_counts / max(1, class_counts.sum())                          # :257
+        priors = (priors + 1e-6) / (priors.sum() + 1e-6 * K)                        # :258
+        # per-class means (:263-284); the reference's second pass recomputes the same represent()
+        self.z_class_mean = torch.zeros(K, Dz, device=self.device)
+        self.z_class_count = torch.zeros(K, device=self.device)
+        for z, y_idx in zip(zs, ys):
+            for k in range(K):
+                m = (y_idx == k)
+                if m.any():
+                    self.z_class_mean[k] += z[m].sum(0)
+                    self.z_class_count[k] += m.sum()
+        for k in range(K):
+            if self.z_class_count[k] > 0:
+                self.z_class_mean[k] /= self.z_class_count[k]
+            else:
+                self.z_class_mean[k] = mean_z.clone()
+        self.joint_rbm.vis_bias.data[:Dz] = torch.log(mean_z) - torch.log1p(-mean_z)   # :291
+        self.joint_rbm.vis_bias.data[Dz:Dz + K] = torch.log(priors)                    # :292
+
+    # ---- pretrained image stack (imdbn.py:294-384) -----------------------------------------------
+    def load_pretrained_image_idbn(self, path: str) -> bool:
+        try:
+            with open(path, "rb") as f:
+                obj = pickle.load(f)
+        except Exception as e:
+            print(f"[load_pretrained_image_idbn] error: {e}")
+            return False
+        if isinstance(obj, dict) and "layers" in obj:
+            self.image_idbn.layers = obj["layers"]
+        elif hasattr(obj, "layers"):
+            self.image_idbn = obj
+            if not hasattr(self.image_idbn, "text_flag"):
+                self.image_idbn.text_flag = False
+            if not hasattr(self.image_idbn, "arch_dir"):
+                self.image_idbn.arch_dir = os.path.join("logs-idbn", "loaded")
+                os.makedirs(self.image_idbn.arch_dir, exist_ok=True)
+        else:
+            print("[load_pretrained_image_idbn] unrecognized format")
+            return False
+        for rbm in self.image_idbn.layers:                                          # :325-333
+            rbm.W = nn.Parameter(rbm.W.data.to(self.device), requires_grad=False)
+            rbm.hid_bias = nn.Parameter(rbm.hid_bias.data.to(self.device), requires_grad=False)
+            rbm.vis_bias = nn.Parameter(rbm.vis_bias.data.to(self.device), requires_grad=False)
+            rbm.W_m = torch.zeros_like(rbm.W)
+            rbm.hb_m = torch.zeros_like(rbm.hid_bias)
+            rbm.vb_m = torch.zeros_like(rbm.vis_bias)
+            if not hasattr(rbm, "softmax_groups"):
+                rbm.softmax_groups = []
+        dz_pre = int(self.image_idbn.layers[-1].num_hidden)
+        if dz_pre != getattr(self, "Dz_img", dz_pre):
+            print(f"[load_pretrained_image_idbn] rebuilding joint: Dz_img -> {dz_pre}")
+            self._build_joint(Dz_img=dz_pre, joint_hidden=self.joint_rbm.num_hidden)
+        print(f"[load_pretrained_image_idbn] loaded from {path}")
+        return True
+
+    def finetune_image_last_layer(self, epochs: int = 0, lr_scale: float = 0.3, cd_k: Optional[int] = None):
+        if epochs <= 0:
+            return
+        last = self.image_idbn.layers[-1]
+        old_lr = float(last.lr)
+        last.lr = max(1e-8, old_lr * float(lr_scale))                               # :363
+        use_cd = int(cd_k) if cd_k is not None else int(self.image_idbn.cd_k)
+        print(f"[finetune_image_last_layer] epochs={epochs}, lr={last.lr:.4g}, CD={use_cd}")
+        self.finetune_losses = []
+        for ep in range(int(epochs)):
+            losses = []
+            for img, _ in self.dataloader:
+                v = img.to(self.device).view(img.size(0), -1).float()
+                for rbm in self.image_idbn.layers[:-1]:
+                    v = rbm.forward(v)
+                losses.append(last.train_epoch(v, ep, epochs, CD=use_cd))
+            if losses:
+                self.finetune_losses.append(torch.stack(losses).cpu())
+        last.lr = old_lr
+        print("[finetune_image_last_layer] done")
+
+    # ---- cross-modal inference (imdbn.py:386-488) -------------------------------------------------
+    @torch.no_grad()
+    def _cross_reconstruct(self, z_img: torch.Tensor, y_onehot: torch.Tensor,
+                           steps: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Returns (img_from_txt [B,D], p_y_given_img [B,K]).
+
+        The reference's best-of-K refinement is inert (RBM has no ``free_energy``; every candidate
+        energy is 0 and argmin picks the main chain, imdbn.py:455-474), so the 4 one-step
+        refinement passes are not computed here -- but their draws ARE consumed so that the random
+        stream stays aligned with the reference.
+        """
+        if steps is None:
+            steps = self.cross_steps
+        B, Dz, K = z_img.size(0), self.Dz_img, self.num_labels
+        V = Dz + K
+        jr = self.joint_rbm
+        # IMG -> TXT (:419-427)
+        v_known = torch.zeros(B, V, device=self.device)
+        km = torch.zeros_like(v_known)
+        v_known[:, :Dz] = z_img
+        km[:, :Dz] = 1.0
+        v_img2txt = jr.conditional_gibbs(v_known, km, n_steps=steps, sample_h=False, sample_v=False)
+        p_y_given_img = v_img2txt[:, Dz:]
+        # TXT -> IMG with mu-pull (:430-449)
+        v_known.zero_()
+        km.zero_()
+        v_known[:, Dz:] = y_onehot
+        km[:, Dz:] = 1.0
+        if getattr(self, "z_class_mean", None) is not None:
+            jr._mu_pull = {"mu_k": self.z_class_mean[y_onehot.argmax(dim=1)], "eta0": 0.15}
+        else:
+            jr._mu_pull = None
+        v_chain = jr.noisy_meanfield_annealed(v_known=v_known, known_mask=km, n_steps=steps, T0=3.0, T1=1.0,
+                                              sigma0=0.9, hot_frac=0.7, sharpen_last=3, T_cold_plus=0.9)
+        # dead refinement passes (:460-474): each would draw one U[B,V] at its chain init (rbm.py:333)
+        _E.get_engine(jr.W.data).skip_draws(_E.get_rng(), [("u", V)] * (KBUF - 1), B)
+        jr._mu_pull = None                                                          # :476
+        z_from_y = v_chain[:, :Dz]
+        if hasattr(self, "z_affine_scale") and hasattr(self, "z_affine_bias"):       # :481-484
+            z_from_y = (z_from_y - self.z_affine_bias) / (self.z_affine_scale + 1e-6)
+        return self.image_idbn.decode(z_from_y), p_y_given_img
+
+    @torch.no_grad()
+    def represent(self, batch: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+        """imdbn.py:501-506."""
+        img_data, lbl_data = batch
+        img = img_data.to(self.device).view(img_data.size(0), -1).float()
+        y = lbl_data.to(self.device).float()
+        return self.joint_rbm.forward(torch.cat([self.image_idbn.represent(img), y], dim=1))
+
+    # ---- joint training (imdbn.py:508-639) --------------------------------------------------------
+    def _clamp_y(self, y, B, V, Dz):
+        vk = torch.zeros(B, V, device=self.device)
+        km = torch.zeros(B, V, device=self.device)
+        vk[:, Dz:] = y
+        km[:, Dz:] = 1.0
+        return vk, km
+
+    def train_joint(self, epochs: int, log_every_pca: int = 25, log_every_probe: int = 10, log_every: int = 5,
+                    w_rec: float = 1.0, w_sup: float = 0.0):
+        """Warm-up (epochs < 8): 2x label-clamped CD per batch; then free CD + label-clamped CD
+        (+ image-clamped CD every 50th batch); `_cross_reconstruct` metrics on EVERY batch.
+
+        Metric accumulators stay on the device and are fetched once per epoch
+        (``self.joint_history``); the reference syncs 4x per batch (imdbn.py:635-638).
+        """
+        print("[iMDBN] joint training (with warmup y-clamp)")
+        self.init_joint_bias_from_data(n_batches=10)
+        jr = self.joint_rbm
+        self.joint_history = []
+        for epoch in range(int(epochs)):
+            cd_losses = []
+            acc = torch.zeros(5, device=self.device, dtype=torch.float64)   # n, top1, top3, ce_sum, mse_sum
+            npix = None
+            for b_idx, (img, y) in enumerate(self.dataloader):
+                img = img.to(self.device).view(img.size(0), -1).float()
+                y = y.to(self.device).float()
+                with torch.no_grad():
+                    z_img = self.image_idbn.represent(img)
+                    v_plus = torch.cat([z_img, y], dim=1)
+                B, Dz, K = z_img.size(0), self.Dz_img, self.num_labels
+                V = Dz + K
+                aux_cond_steps = int(self.params.get("JOINT_AUX_COND_STEPS", 10))   # :564
+                if epoch < WARMUP_Y_EPOCHS:                                          # :566-579
+                    for _ in range(2):
+                        vk, km = self._clamp_y(y, B, V, Dz)
+                        jr.train_epoch_clamped(vk, km, epoch, epochs, CD=1, cond_init_steps=aux_cond_steps,
+                                               sample_h=False, sample_v=False, aux_lr_mult=0.3, use_noisy_init=True)
+                else:                                                                # :582-612
+                    cd_losses.append(jr.train_epoch(v_plus, epoch, epochs, CD=self.joint_cd))
+                    vk, km = self._clamp_y(y, B, V, Dz)
+                    jr.train_epoch_clamped(vk, km, epoch, epochs, CD=1, cond_init_steps=aux_cond_steps,
+                                           sample_h=False, sample_v=False, reclamp_negative=False,
+                                           aux_lr_mult=0.3, use_noisy_init=True)
+                    if (b_idx % Z_CLAMP_EVERY) == 0:
+                        vk.zero_()
+                        km.zero_()
+                        vk[:, :Dz] = z_img
+                        km[:, :Dz] = 1.0
+                        jr.train_epoch_clamped(vk, km, epoch, epochs, CD=1, cond_init_steps=aux_cond_steps,
+                                               sample_h=False, sample_v=False, reclamp_negative=False,
+                                               aux_lr_mult=0.3, use_noisy_init=True)
+                with torch.no_grad():                                                # :615-639
+                    img_from_txt, p_y = self._cross_reconstruct(z_img, y, steps=self.cross_steps)
+                    gt = y.argmax(dim=1)
+                    pred = p_y.argmax(dim=1)
+                    topk_idx = p_y.topk(k=min(3, p_y.size(1)), dim=1).indices
+                    ce = F.binary_cross_entropy(p_y.clamp(1e-6, 1 - 1e-6),
+                                                F.one_hot(gt, num_classes=p_y.size(1)).float(), reduction="sum")
+                    mse = F.mse_loss(img_from_txt.view_as(img), img, reduction="sum")
+                    npix = img.size(1)
+                    acc += torch.stack([torch.tensor(float(B), device=self.device, dtype=torch.float64),
+                                        (pred == gt).sum().double(),
+                                        (topk_idx == gt.unsqueeze(1)).any(dim=1).sum().double(),
+                                        ce.double(), mse.double()])
+            a = acc.cpu()
+            n = max(1.0, float(a[0]))
+            rec = {"epoch": epoch, "n": int(a[0]), "text_top1": float(a[1]) / n, "text_top3": float(a[2]) / n,
+                   "text_ce": float(a[3]) / n, "image_mse": float(a[4]) / max(1.0, n * max(1, npix or 1)),
+                   "cd_loss": float(torch.stack(cd_losses).mean()) if cd_losses else None,
+                   "cd_losses": torch.stack(cd_losses).cpu() if cd_losses else None}
+            self.joint_history.append(rec)
+            if self.wandb_run:
+                if rec["cd_loss"] is not None:
+                    self.wandb_run.log({"joint/cd_loss": rec["cd_loss"], "epoch": epoch})
+                self.wandb_run.log({"cross_modality/text_top1": rec["text_top1"], "cross_modality/text_top3": rec["text_top3"],
+                                    "cross_modality/text_ce": rec["text_ce"], "cross_modality/image_mse": rec["image_mse"],
+                                    "epoch": epoch})
+        print("[iMDBN] joint training finished.")
+
+    # ---- persistence (imdbn.py:815-934) -------------------------------------
+    def save_model(self, path: str):
+        all_layers = list(self.image_idbn.layers) + [self.joint_rbm]
+        payload = {
+            "layers": all_layers, "params": self.params,
+            "image_idbn": self.image_idbn, "joint_rbm": self.joint_rbm, "num_labels": self.num_labels,
+            "Dz_img": self.Dz_img, "arch_str": self.arch_str, "features": self.features,
+            "metadata": {"saved_at": datetime.datetime.now().isoformat(), "model_type": "iMDBN",
+                         "architecture": self.arch_str},
+        }
+        for k in ("z_class_mean", "z_affine_scale", "z_affine_bias", "class_names"):
+            if getattr(self, k, None) is not None:
+                payload[k] = getattr(self, k)
+        with open(path, "wb") as f:
+            pickle.dump(payload, f)
+        print(f"[iMDBN] Model saved to {path}")
+
+    @staticmethod
+    def load_model(path: str, device=None) -> Dict[str, Any]:
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        with open(path, "rb") as f:
+            payload = pickle.load(f)
+        if "image_idbn" in payload:
+            for rbm in payload["image_idbn"].layers:
+                rbm.to(device)
+        if "joint_rbm" in payload:
+            payload["joint_rbm"].to(device)
+        print(f"[iMDBN] Model loaded from {path}")
+        return payload

@@ -1,0 +1,251 @@
+"""RBM with the reference's class surface, backed by the MI355X CD engine.
+
+API mirror of the reference ``imdbn/models/rbm.py`` (same constructor, method names, keyword
+defaults, attribute names and pickle state -- SURVEY.md 8b-1 / Appendix C), but every method body
+is host-side scalar logic plus ONE call into the native engine (``imdbn.engine``): no ATen
+arithmetic on the hot path.  Reference line numbers are cited per method.
+
+Deliberate differences: random draws come from the engine's RNG source
+(``imdbn.engine.get_rng()``: device Philox by default, recorded draws in the parity tests) instead
+of torch's global generator; all returned tensors are grad-less.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from imdbn import engine as _E
+
+
+def _step(T=1.0, sigma=0.0, eta=0.0, sample_h=False, vmode=0, clamp=True) -> dict:
+    return {"T": float(T), "sigma": float(sigma), "eta": float(eta), "sample_h": bool(sample_h),
+            "vmode": int(vmode), "clamp": bool(clamp)}
+
+
+class RBM(nn.Module):
+    """Bernoulli RBM with optional softmax groups on the visible layer (reference rbm.py:24-79)."""
+
+    def __init__(
+        self,
+        num_visible: int,
+        num_hidden: int,
+        learning_rate: float,
+        weight_decay: float,
+        momentum: float,
+        dynamic_lr: bool = False,
+        final_momentum: float = 0.97,
+        sparsity: bool = False,
+        sparsity_factor: float = 0.05,
+        softmax_groups: Optional[List[Tuple[int, int]]] = None,
+    ):
+        super().__init__()
+        self.num_visible = int(num_visible)
+        self.num_hidden = int(num_hidden)
+        self.lr = float(learning_rate)
+        self.weight_decay = float(weight_decay)
+        self.momentum = float(momentum)
+        self.dynamic_lr = bool(dynamic_lr)
+        self.final_momentum = float(final_momentum)
+        self.sparsity = bool(sparsity)
+        self.sparsity_factor = float(sparsity_factor)
+        self.softmax_groups = softmax_groups or []
+
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")      # rbm.py:69
+        self.W = nn.Parameter(
+            torch.randn(self.num_visible, self.num_hidden, device=device) / math.sqrt(max(1, self.num_visible)),
+            requires_grad=False)
+        self.hid_bias = nn.Parameter(torch.zeros(self.num_hidden, device=device), requires_grad=False)
+        self.vis_bias = nn.Parameter(torch.zeros(self.num_visible, device=device), requires_grad=False)
+        # momentum buffers: plain attributes, exactly as in the reference (rbm.py:77-79)
+        self.W_m = torch.zeros_like(self.W)
+        self.hb_m = torch.zeros_like(self.hid_bias)
+        self.vb_m = torch.zeros_like(self.vis_bias)
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _eng(self):
+        return _E.get_engine(self.W.data)
+
+    def _in(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.W.device, dtype=torch.float32)
+
+    def _mu(self):
+        mp = getattr(self, "_mu_pull", None)                                        # rbm.py:359
+        if mp is None:
+            return None, 0.0
+        return self._in(mp["mu_k"]), float(mp.get("eta0", 0.15))
+
+    def _lr_mom(self, epoch: int):
+        lr = self.lr / (1 + 0.01 * epoch) if self.dynamic_lr else self.lr          # rbm.py:194
+        mom = self.momentum if epoch <= 5 else self.final_momentum                  # rbm.py:195
+        return lr, mom
+
+    # ---- propagations (rbm.py:81-178) ---------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, v: torch.Tensor, T: float = 1.0) -> torch.Tensor:
+        """p(h|v) = sigmoid((v W + c)/max(1e-6,T))   (rbm.py:92)."""
+        return self._eng().prop_up(self, self._in(v), T=T)
+
+    @torch.no_grad()
+    def _visible_logits(self, h: torch.Tensor, T: float = 1.0) -> torch.Tensor:
+        """(h W^T + b)/max(1e-6,T)   (rbm.py:96)."""
+        return self._eng().prop_down(self, self._in(h), T=T, logits_only=True)
+
+    @torch.no_grad()
+    def visible_probs(self, h: torch.Tensor, T: float = 1.0) -> torch.Tensor:
+        """p(v|h) with softmax over each group (rbm.py:109-116)."""
+        return self._eng().prop_down(self, self._in(h), T=T)
+
+    @torch.no_grad()
+    def sample_visible(self, v_prob: torch.Tensor) -> torch.Tensor:
+        """Bernoulli over all columns, one categorical per softmax group (rbm.py:125-135)."""
+        return self._eng().sample_visible(self, self._in(v_prob), _E.get_rng())
+
+    @torch.no_grad()
+    def backward(self, h: torch.Tensor, return_logits: bool = False) -> torch.Tensor:
+        """Decoder alias of visible_probs at T=1 (rbm.py:148-151)."""
+        if return_logits:
+            return self._visible_logits(h)
+        return self.visible_probs(h)
+
+    @torch.no_grad()
+    def backward_sample(self, h: torch.Tensor) -> torch.Tensor:
+        """rbm.py:156."""
+        return self.sample_visible(self.visible_probs(h))
+
+    @torch.no_grad()
+    def gibbs_step(self, v: torch.Tensor, sample_h: bool = True, sample_v: bool = True):
+        """One v -> h -> v' step; returns (v_next, v_prob, h, h_prob)   (rbm.py:174-178)."""
+        return self._eng().gibbs_step(self, self._in(v), sample_h, sample_v, _E.get_rng())
+
+    # ---- CD-k update (rbm.py:180-227) -----------------------------------------------------------
+    @torch.no_grad()
+    def train_epoch(self, data: torch.Tensor, epoch: int, max_epochs: int, CD: int = 1):
+        """One CD-k update on one mini-batch (the name is the reference's); returns the 0-d MSE loss.
+
+        With data parallelism enabled (``imdbn.engine.dp.enable()``) ``data`` is this rank's shard
+        of the global batch: statistics are all-reduced once and every replica applies the same
+        update with 1/global_batch.
+        """
+        lr, mom = self._lr_mom(epoch)
+        eng, rng, x = self._eng(), _E.get_rng(), self._in(data)
+        dp = _E.dp
+        if dp.active():
+            B = x.size(0)
+            if isinstance(rng, _E.PhiloxRng):
+                rng.row0 = dp.rank() * B
+            packed = eng.cd_stats(self, x, CD, rng)
+            dp.all_reduce_sum(packed)
+            return eng.apply_delta(self, packed, B * dp.world_size(), lr, mom)
+        return eng.cd_step(self, x, lr, mom, CD, rng)
+
+    # ---- schedules (rbm.py:229-238) -------------------------------------------------------------
+    def _lin_schedule(self, t, t_max, start, end):
+        if t_max <= 1:
+            return float(end)
+        alpha = min(max(t / (t_max - 1), 0.0), 1.0)
+        return float(start + (end - start) * alpha)
+
+    def _hot_steps(self, n_steps, hot_frac):
+        return int(max(0, min(n_steps, round(hot_frac * n_steps))))
+
+    def _nmf_steps(self, n_steps, T0, T1, sigma0, sharpen_last, T_cold_plus, eta0) -> List[dict]:
+        """Host scalars of rbm.py:337-341,362 for each step of noisy mean-field annealing."""
+        n = int(n_steps)
+        steps = []
+        for t in range(n):
+            Tt = self._lin_schedule(t, n, T0, T1)
+            if (n - t) <= max(1, int(sharpen_last)):
+                Tt = T_cold_plus
+            frac = max(0.0, 1.0 - (t / max(1, n - 1)))
+            steps.append(_step(T=Tt, sigma=sigma0 * frac, eta=eta0 * frac, sample_h=False, vmode=0, clamp=True))
+        return steps
+
+    # ---- chains (rbm.py:240-400) ---------------------------------------------------------------
+    @torch.no_grad()
+    def conditional_gibbs_annealed(
+        self,
+        v_known: torch.Tensor,
+        known_mask: torch.Tensor,
+        n_steps: int = 40,
+        T0: float = 2.5,
+        T1: float = 1.0,
+        sample_h_until: int = 20,
+        sample_v_every: int = 0,
+        final_meanfield: bool = True,
+    ):
+        """rbm.py:270-298."""
+        n = int(n_steps)
+        hot = int(max(0, min(n_steps, sample_h_until)))
+        steps = []
+        for t in range(n):
+            Tt = self._lin_schedule(t, n, T0, T1)
+            if (n - t) <= 3:
+                Tt = min(0.9, Tt)
+            sv = (t < hot) and (sample_v_every > 0) and (t % sample_v_every == 0)
+            steps.append(_step(T=Tt, sample_h=(t < hot), vmode=1 if sv else 0, clamp=True))
+        if final_meanfield:
+            steps.append(_step(T=1.0, clamp=True))
+        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, _E.get_rng())
+
+    @torch.no_grad()
+    def noisy_meanfield_annealed(
+        self,
+        v_known: torch.Tensor,
+        known_mask: torch.Tensor,
+        n_steps: int = 72,
+        T0: float = 3.0,
+        T1: float = 1.0,
+        sigma0: float = 0.9,
+        hot_frac: float = 0.7,
+        sharpen_last: int = 3,
+        T_cold_plus: float = 0.9,
+    ):
+        """rbm.py:332-367 (``hot_frac`` is accepted and, as in the reference, has no effect)."""
+        mu, eta0 = self._mu()
+        steps = self._nmf_steps(n_steps, T0, T1, sigma0, sharpen_last, T_cold_plus, eta0 if mu is not None else 0.0)
+        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, _E.get_rng(), mu=mu)
+
+    @torch.no_grad()
+    def conditional_gibbs(
+        self,
+        v_known: torch.Tensor,
+        known_mask: torch.Tensor,
+        n_steps: int = 30,
+        sample_h: bool = False,
+        sample_v: bool = False,
+    ) -> torch.Tensor:
+        """rbm.py:391-400; the last entry is the reference's final UN-clamped pass (:400)."""
+        steps = [_step(sample_h=sample_h, vmode=1 if sample_v else 0, clamp=True) for _ in range(int(n_steps))]
+        steps.append(_step(clamp=False))
+        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, _E.get_rng())
+
+    # ---- clamped CD (rbm.py:402-483) -------------------------------------------------------------
+    @torch.no_grad()
+    def train_epoch_clamped(
+        self,
+        v_known: torch.Tensor,
+        known_mask: torch.Tensor,
+        epoch: int,
+        max_epochs: int,
+        CD: int = 1,
+        cond_init_steps: int = 50,
+        sample_h: bool = True,
+        sample_v: bool = False,
+        reclamp_negative: bool = True,
+        aux_lr_mult: float = 0.3,
+        use_noisy_init: bool = True,
+    ):
+        """Auxiliary clamped CD update; returns the 0-d loss mean((v+ - v-)^2)."""
+        lr, mom = self._lr_mom(epoch)
+        mu = None
+        if use_noisy_init:                                                          # rbm.py:443-448
+            mu, eta0 = self._mu()
+            init = self._nmf_steps(max(10, int(cond_init_steps)), 3.0, 1.0, 0.9, 2, 0.9, eta0 if mu is not None else 0.0)
+        else:                                                                       # rbm.py:450-453
+            init = [_step(sample_h=sample_h, vmode=1 if sample_v else 0, clamp=True) for _ in range(int(cond_init_steps))]
+            init.append(_step(clamp=False))
+        return self._eng().clamped_step(self, self._in(v_known), self._in(known_mask), init, mu,
+                                        aux_lr_mult * lr, mom, CD, sample_h, sample_v, reclamp_negative, _E.get_rng())

@@ -1,0 +1,41 @@
+"""CPU-only: the product's host logic (RBM/iDBN/iMDBN method bodies, step schedules, draw order)
+against the reference fixtures, with the oracle-backed TEST DOUBLE standing in for the HIP engine.
+No claim about the kernels is made here -- those are tested on the GPU in test_parity_gpu.py."""
+import pytest
+import torch
+
+import parity_cases as P
+from imdbn import engine as E
+from oracle_engine import OracleEngine
+
+
+@pytest.fixture(autouse=True)
+def _double():
+    E.set_engine_for_testing(OracleEngine())
+    yield
+    E.set_engine_for_testing(None)
+
+
+def test_c1_host_logic():
+    P.case_c1("cpu", rel=2e-5)
+
+
+def test_joint_small_host_logic():
+    P.case_joint_small("cpu", rel=5e-5)
+
+
+def test_idbn_small_host_logic():
+    P.case_idbn_small("cpu", rel=5e-5)
+
+
+def test_imdbn_small_host_logic():
+    P.case_imdbn_small("cpu", rel=2e-4)
+
+
+def test_product_refuses_cpu_without_engine():
+    """No silent CPU fallback: without the test double a CPU tensor must raise."""
+    E.set_engine_for_testing(None)
+    from imdbn.models import RBM
+    r = RBM(8, 4, 0.1, 1e-4, 0.5).to("cpu")
+    with pytest.raises(E.EngineError):
+        r.forward(torch.zeros(2, 8))

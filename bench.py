@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- CD-1 updates/s of the headline RBM (10000 <-> 1500, batch 64 per GPU) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete ``RBM.train_epoch`` call (reference rbm.py:180-227) on the global batch:
+K1 -> K2 -> K1 -> K3 (+ epilogue kernels), called through the product's Python class exactly as
+``iDBN.train`` calls it (idbn.py:202).  Inputs (16 distinct synthetic binary 100x100 "dot" frames
+batches, density 0.1) are resident in HBM before the timed region.  With N>1 each rank holds a
+full parameter replica and 64 rows of a 64*N global batch; one all-reduce (RCCL) of the packed
+statistics per step; `value` counts global updates per second (weak scaling).
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel (K3 assoc_update): algorithmic bytes
+16*V*H per launch over the HIP-event-measured mean launch time on the launch stream.
+`cpu_baseline` times the numpy oracle (a port of the reference arithmetic) on the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "multimodal-idbn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+V, H, B = 10000, 1500, 64
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
+
+
+def cpu_baseline(max_seconds: float = 12.0, max_updates: int = 60):
+    """numpy oracle ("port" of rbm.py:194-227) on the identical workload; bounded sample."""
+    import numpy as np
+    import oracle.rbm_oracle as O
+    from oracle.draws import DrawStream
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    s = DrawStream(1)
+    st = O.RBMState.create((s.normal((V, H)) / np.float32(100.0)).astype(np.float32), 0.1, 1e-4, 0.5,
+                           dynamic_lr=True, final_momentum=0.95)
+    X = (s.uniform((B, V)) > 0.9).astype(np.float32)
+    for _ in range(2):
+        O.train_epoch(st, X, 0, 1, s)
+    n, t0 = 0, time.perf_counter()
+    while n < max_updates and time.perf_counter() - t0 < max_seconds:
+        O.train_epoch(st, X, 0, 1, s)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "updates/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} CD-1 updates of the same 10000x1500 batch-64 workload, numpy/OpenBLAS oracle, "
+                      f"{os.cpu_count()} host cpus visible"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="parity", choices=["parity", "fast"])
+    ap.add_argument("--ksplit-up", type=int, default=0)
+    ap.add_argument("--ksplit-down", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from imdbn import engine as E
+    from imdbn.engine import native
+    from imdbn.models import RBM
+
+    eng = E.hip_engine()
+    eng.mode = native.FAST_BF16 if args.mode == "fast" else native.PARITY_F32
+    if args.ksplit_up or args.ksplit_down:
+        eng.set_tuning(args.ksplit_up, args.ksplit_down)
+    if world > 1:
+        E.dp.enable()
+
+    torch.manual_seed(0)
+    rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
+    if world > 1:      # identical replicas
+        for t in (rbm.W.data, rbm.hid_bias.data, rbm.vis_bias.data):
+            dist.broadcast(t, 0)
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    batches = [(torch.rand(B, V, generator=g) > 0.9).float().to(dev) for _ in range(16)]
+    E.set_rng(E.PhiloxRng(seed=2, row0=rank * B))
+
+    def step(i):
+        return rbm.train_epoch(batches[i % len(batches)], 0, 1, CD=1)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    if world == 1:
+        eng.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    k3_ms, k3_n = (eng.profile_read() if world == 1 else (0.0, 0))
+    if world == 1:
+        eng.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        ups = args.steps / dt
+        out = {
+            "metric": "CD-1 updates/sec (batch 64, 10000<->1500 RBM)",
+            "value": ups, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.mode == "parity" else "bf16",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] layer 1: RBM 10000<->1500 train_epoch, CD-1, batch 64 per GPU, "
+                                   "fp32 master weights, lr 0.1 wd 1e-4 mom 0.5",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
+                       "final_loss": float(loss)},
+            "frac_hbm_roofline_whole_step": ups * 16.0 * V * H / (HBM_PEAK_GBS * 1e9),
+            "frac_bf16_mfma_roofline_whole_step": ups * 10.0 * B * V * H / (BF16_PEAK_TFLOPS * 1e12),
+        }
+        if world == 1 and k3_n > 0:
+            avg_s = 1e-3 * k3_ms / k3_n
+            ach = 16.0 * V * H / avg_s / 1e9
+            out["roofline"] = {"kernel": "assoc_update (K3)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_us": 1e6 * avg_s, "launches": k3_n,
+                               "algorithmic_bytes_per_launch": 16 * V * H}
+        else:
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the reference fixtures and the oracle.
+
+Tolerance (north_star): <= 1e-4 relative (Frobenius) on weights; the replayed draws are the ones the
+reference consumed, so any larger deviation is a kernel bug or a Bernoulli flip at a sub-1e-6 margin
+(the assertion message says which).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle.rbm_oracle as O
+import parity_cases as P
+from golden_utils import Fixture, assert_close, init_W, rel_fro
+from oracle.draws import DrawStream, PhiloxStream
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _native():
+    import __graft_entry__ as ge
+    ge.build()
+    from imdbn import engine as E
+    E.set_engine_for_testing(None)
+    eng = E.hip_engine()             # raises if the library is missing: no silent fallback
+    cu, arch = eng.device_info()
+    assert "gfx950" in arch, arch
+    yield eng
+
+
+def test_c1_fixture_gpu():
+    P.case_c1(DEV, rel=1e-4)
+
+
+def test_joint_small_fixture_gpu():
+    P.case_joint_small(DEV, rel=1e-4)
+
+
+def test_idbn_small_fixture_gpu():
+    P.case_idbn_small(DEV, rel=1e-4)
+
+
+def test_imdbn_small_fixture_gpu():
+    P.case_imdbn_small(DEV, rel=3e-4)
+
+
+def _mk(V, H, groups=None, seed=0, **kw):
+    from imdbn.models import RBM
+    g = np.random.Generator(np.random.PCG64(seed))
+    W0 = (g.standard_normal((V, H), dtype=F32) / F32(np.sqrt(V))).astype(F32)
+    hb = (g.standard_normal(H, dtype=F32) * F32(0.1)).astype(F32)
+    vb = (g.standard_normal(V, dtype=F32) * F32(0.1)).astype(F32)
+    r = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=groups, **kw)
+    P.set_params(r, DEV, W0, hb, vb)
+    st = O.RBMState.create(W0, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=groups,
+                           hid_bias=hb, vis_bias=vb, **kw)
+    return r, st, g
+
+
+@pytest.mark.parametrize("V,H,B,groups", [
+    (64, 64, 64, None),            # exactly one tile
+    (37, 19, 1, None),             # odd sizes, batch 1, unaligned rows (scalar weight loads)
+    (130, 70, 33, None),           # ragged tiles, batch not a multiple of 32
+    (200, 96, 100, [(190, 200)]),  # batch > 64 (two M blocks), softmax group at the edge
+    (300, 128, 64, [(10, 20), (290, 300)]),   # two groups, one straddling nothing, one at the end
+    (1000, 260, 64, None),         # several split-K chunks
+])
+def test_philox_cd_step_matches_oracle(V, H, B, groups):
+    """PHILOX mode: device draws == oracle/draws.py:PhiloxStream, so the whole update must agree."""
+    from imdbn import engine as E
+    r, st, g = _mk(V, H, groups, seed=V + H, sparsity=True, sparsity_factor=0.1)
+    X = (g.random((B, V), dtype=F32) > 0.6).astype(F32)
+    Xr = g.random((B, V), dtype=F32)
+    with E.use_rng(E.PhiloxRng(seed=99)):
+        l1 = r.train_epoch(P.T(X, DEV), 2, 10, CD=2)
+        l2 = r.train_epoch(P.T(Xr, DEV), 7, 10, CD=1)
+    ps = PhiloxStream(99)
+    o1 = O.train_epoch(st, X, 2, 2, ps)
+    o2 = O.train_epoch(st, Xr, 7, 1, ps)
+    assert_close(np.array([float(l1), float(l2)], F32), np.array([o1, o2], F32), 1e-5, "losses")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
+
+
+@pytest.mark.parametrize("B", [5, 64])
+def test_philox_chains_and_clamped_match_oracle(B):
+    from imdbn import engine as E
+    V, H, Dz = 150, 48, 140
+    r, st, g = _mk(V, H, [(Dz, V)], seed=3)
+    z = g.random((B, Dz), dtype=F32)
+    y = np.eye(V - Dz, dtype=F32)[np.arange(B) % (V - Dz)]
+    vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+    vk[:, Dz:] = y; km[:, Dz:] = 1
+    mu = g.random((B, Dz), dtype=F32)
+    with E.use_rng(E.PhiloxRng(seed=5)):
+        a = r.conditional_gibbs(P.T(vk, DEV), P.T(km, DEV), n_steps=7, sample_h=True, sample_v=True)
+        r._mu_pull = {"mu_k": P.T(mu, DEV), "eta0": 0.15}
+        b = r.noisy_meanfield_annealed(P.T(vk, DEV), P.T(km, DEV), n_steps=15)
+        r._mu_pull = None
+        c = r.conditional_gibbs_annealed(P.T(vk, DEV), P.T(km, DEV), n_steps=9, sample_h_until=5, sample_v_every=2)
+        l = r.train_epoch_clamped(P.T(vk, DEV), P.T(km, DEV), 1, 10, CD=2, cond_init_steps=12, sample_h=True,
+                                  sample_v=True, reclamp_negative=True)
+    ps = PhiloxStream(5)
+    assert_close(P.N(a), O.conditional_gibbs(st, vk, km, ps, n_steps=7, sample_h=True, sample_v=True), 1e-4, "cg")
+    st.mu_pull = {"mu_k": mu, "eta0": 0.15}
+    assert_close(P.N(b), O.noisy_meanfield_annealed(st, vk, km, ps, n_steps=15), 1e-4, "nmf")
+    st.mu_pull = None
+    assert_close(P.N(c), O.conditional_gibbs_annealed(st, vk, km, ps, n_steps=9, sample_h_until=5, sample_v_every=2),
+                 1e-4, "cga")
+    lo = O.train_epoch_clamped(st, vk, km, 1, ps, CD=2, cond_init_steps=12, sample_h=True, sample_v=True,
+                               reclamp_negative=True)
+    assert_close(float(l), lo, 1e-4, "clamped loss")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
+
+
+def test_products_are_fp32_exact():
+    """bf16x3 split: v@W against float64 must be at fp32 rounding level (not bf16 level)."""
+    r, st, g = _mk(2000, 300, None, seed=11)
+    x = g.random((64, 2000), dtype=F32)
+    logits_gpu = None
+    p = P.N(r.forward(P.T(x, DEV)))
+    ref = 1.0 / (1.0 + np.exp(-((x.astype(np.float64) @ st.W.astype(np.float64)) + st.hid_bias)))
+    assert np.abs(p - ref).max() < 5e-7, np.abs(p - ref).max()
+    h = g.random((64, 300), dtype=F32)
+    lg = P.N(r.backward(P.T(h, DEV), return_logits=True))
+    ref = (h.astype(np.float64) @ st.W.T.astype(np.float64)) + st.vis_bias
+    assert np.abs(lg - ref).max() < 2e-5 * np.abs(ref).max() + 2e-6
+
+
+def test_c2_headline_digest_gpu():
+    """Full-size 10000<->1500, batch 64: 3 updates against the reference's digests."""
+    from imdbn import engine as E
+    from imdbn.models import RBM
+    fx = Fixture("c2_rbm10000x1500_cd1_digest.npz")
+    m = fx.meta
+    s = fx.stream()
+    Vv, Hh, B, U = m["V"], m["H"], m["B"], m["updates"]
+    r = RBM(Vv, Hh, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95)
+    P.set_params(r, DEV, init_W(s, Vv, Hh))
+    X = (s.uniform((B * U, Vv)) > 0.9).astype(F32)
+    with E.use_rng(E.ReplayRng(s)):
+        losses = [float(r.train_epoch(P.T(X[B * i:B * i + B], DEV), 0, 10, CD=1)) for i in range(U)]
+    assert_close(np.array(losses, F32), fx["losses"], 2e-5, "losses")
+    for k in ("W", "W_m"):
+        a = P.N(getattr(r, k))
+        assert abs(a.astype(np.float64).sum() - fx[k + "_sum"]) <= 1e-4 * abs(fx[k + "_sum"]) + 1e-2
+        assert abs((a.astype(np.float64) ** 2).sum() - fx[k + "_sumsq"]) <= 1e-4 * fx[k + "_sumsq"]
+        assert_close(a.ravel()[fx[k + "_probe_idx"]], fx[k + "_probe_val"], 1e-4, k + " probes", atol=1e-6)
+    for k in ("hid_bias", "vis_bias", "hb_m", "vb_m"):
+        assert_close(P.N(getattr(r, k)), fx[k], 2e-4, k, atol=1e-6)
+
+
+def test_full_size_properties():
+    """Size-independent properties at the headline size: determinism, shard-invariance of the
+    statistics (sum over 2 row shards == unsharded, PHILOX keyed on the global row), and the
+    fused update == stats + apply."""
+    from imdbn import engine as E
+    from imdbn.models import RBM
+    Vv, Hh, B = 10000, 1500, 64
+    g = np.random.Generator(np.random.PCG64(1))
+    W0 = (g.standard_normal((Vv, Hh), dtype=F32) * F32(0.01)).astype(F32)
+    X = (g.random((B, Vv), dtype=F32) > 0.9).astype(F32)
+    eng = E.hip_engine()
+
+    def fresh():
+        r = RBM(Vv, Hh, 0.1, 1e-4, 0.5)
+        return P.set_params(r, DEV, W0)
+
+    ra, rb = fresh(), fresh()
+    with E.use_rng(E.PhiloxRng(seed=42)):
+        la = ra.train_epoch(P.T(X, DEV), 0, 1)
+    with E.use_rng(E.PhiloxRng(seed=42)):
+        lb = rb.train_epoch(P.T(X, DEV), 0, 1)
+    assert torch.equal(ra.W.data, rb.W.data) and torch.equal(ra.vis_bias.data, rb.vis_bias.data) and float(la) == float(lb)
+
+    rc = fresh()
+    full = eng.cd_stats(rc, P.T(X, DEV), 1, E.PhiloxRng(seed=42))
+    s0 = eng.cd_stats(rc, P.T(X[:32], DEV), 1, E.PhiloxRng(seed=42, row0=0))
+    s1 = eng.cd_stats(rc, P.T(X[32:], DEV), 1, E.PhiloxRng(seed=42, row0=32))
+    assert torch.equal(rc.W.data, P.T(W0, DEV)), "cd_stats must not touch parameters"
+    assert rel_fro(P.N(s0 + s1), P.N(full)) < 1e-5
+    l = eng.apply_delta(rc, s0 + s1, B, 0.1, 0.5)
+    assert rel_fro(P.N(rc.W.data), P.N(ra.W.data)) < 1e-5
+    assert rel_fro(P.N(rc.hid_bias.data), P.N(ra.hid_bias.data)) < 1e-4
+    assert abs(float(l) - float(la)) < 1e-5
+
+
+def test_caller_may_rebind_and_mutate_parameters():
+    """the engine must read parameters at every call."""
+    from imdbn import engine as E
+    r, st, g = _mk(96, 40, None, seed=2)
+    x = g.random((8, 96), dtype=F32)
+    a = P.N(r.forward(P.T(x, DEV)))
+    r.W = torch.nn.Parameter(r.W.data * 2.0, requires_grad=False)        # re-bind (imdbn.py:326)
+    r.hid_bias.data[:] = 0.5                                              # in-place (imdbn.py:291)
+    st.W *= 2; st.hid_bias[:] = 0.5
+    b = P.N(r.forward(P.T(x, DEV)))
+    assert_close(b, O.forward(st, x), 1e-5, "forward after rebind")
+    assert not np.allclose(a, b)
+
+
+def test_abi_errors_are_python_exceptions():
+    from imdbn import engine as E
+    from imdbn.models import RBM
+    r = RBM(32, 16, 0.1, 1e-4, 0.5, softmax_groups=[(0, 4), (4, 8), (8, 12), (12, 16), (16, 20)]).to(DEV)
+    with pytest.raises(E.EngineError):
+        r.visible_probs(torch.zeros(2, 16, device=DEV))
+    r2 = RBM(32, 16, 0.1, 1e-4, 0.5).to(DEV)
+    with pytest.raises(E.EngineError):
+        r2.train_epoch(torch.zeros(4, 32, device=DEV), 0, 1, CD=0)
+
+
+def test_pickle_roundtrip_and_reference_pickle(tmp_path):
+    """Appendix C: reference-written pickles load into engine-backed classes and run on the GPU;
+    our pickles carry only plain tensors/attributes."""
+    import pickle
+    from imdbn.models import iMDBN
+    import os
+    from golden_utils import GOLDEN
+    payload = iMDBN.load_model(os.path.join(GOLDEN, "ref_imdbn_small.pkl"), device=torch.device(DEV))
+    jr = payload["joint_rbm"]
+    fx = Fixture("imdbn_small_100_40_20_j16.npz")
+    assert_close(P.N(jr.W), fx["joint_W"], 1e-7, "pickled joint W")
+    out = jr.forward(torch.rand(4, jr.num_visible, device=DEV))           # momentum buffers stayed on CPU: engine re-homes
+    assert out.shape == (4, jr.num_hidden)
+    l = jr.train_epoch(torch.rand(4, jr.num_visible, device=DEV), 0, 1)
+    assert torch.isfinite(l)
+    p = tmp_path / "rt.pkl"
+    with open(p, "wb") as f:
+        pickle.dump({"layers": [jr]}, f)
+    with open(p, "rb") as f:
+        back = pickle.load(f)["layers"][0]
+    assert torch.equal(back.W.data, jr.W.data) and set(vars(back)) == set(vars(jr))

@@ -94,7 +94,7 @@ def main():
     from imdbn.engine import native
     from imdbn.models import RBM
 
-    eng = E.hip_engine()
+    eng = E.get_hip_engine()
     eng.mode = native.FAST_BF16 if args.mode == "fast" else native.PARITY_F32
     if args.ksplit_up or args.ksplit_down:
         eng.set_tuning(args.ksplit_up, args.ksplit_down)

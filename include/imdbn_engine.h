@@ -120,6 +120,8 @@ int    imdbn_device_info(int* cu_count, char* arch, size_t n);
 size_t imdbn_ws_bytes(int V, int H, int B);
 /* tuning knobs (split-K factors); 0 = automatic */
 int    imdbn_set_tuning(int ksplit_up, int ksplit_down);
+/* named tuning/testing knobs: "ksplit_up", "ksplit_down", "generic_k3" (1 = force the unaligned-shape K3) */
+int    imdbn_set_option(const char* name, int value);
 /* per-kernel timing of the update kernel with HIP events on the launch stream (bench.py roofline) */
 int    imdbn_profile_enable(int on);
 int    imdbn_profile_read(double* total_ms, int* launches);   /* synchronises the recorded events */

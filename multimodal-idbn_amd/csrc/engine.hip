@@ -22,6 +22,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 int g_ks_up = 0, g_ks_down = 0;
+bool g_no_fast_k3 = false;    // tuning/testing: force the generic K3
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -90,7 +91,7 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.V = V; L.H = H; L.B = B;
     L.Bp = rup(std::max(B, 1), 64);
     L.Vpad = rup(V, 16); L.Hpad = rup(H, 16);
-    L.P = L.Bp / 32;
+    L.P = L.Bp / 8;
     const int mb = L.Bp / 64;
     L.up = plan_split(L.Vpad, cdiv(H, 64), mb, g_ks_up, 64);
     L.down = plan_split(L.Hpad, cdiv(V, 64), mb, g_ks_down, 16);
@@ -258,7 +259,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
     dim3 fgrid(cdiv(f.N, 64), L.P);
     if ((int)(fgrid.x * fgrid.y) + IMDBN_MAX_GROUPS > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
-    hipLaunchKernelGGL(finish, fgrid, dim3(256), 0, c.s, f);
+    hipLaunchKernelGGL(finish, fgrid, dim3(64), 0, c.s, f);
     HIPCHK(hipGetLastError());
     if (f.n_groups > 0 && !f.logits_only) {
         hipLaunchKernelGGL(finish_groups, dim3(f.n_groups), dim3(64), 0, c.s, f, (int)(fgrid.x * fgrid.y));
@@ -273,33 +274,17 @@ int n_loss_used(const Ctx& c, bool up) {
 
 // caller fp32 tensor -> operand forms in the workspace
 int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_t* tr, int* flag,
-         float* colsum_unused = nullptr) {
-    (void)colsum_unused;
+         float* colsum = nullptr) {
     PrepArgs p;
     memset(&p, 0, sizeof(p));
     p.in = in; p.ld = ld; p.B = c.L.B; p.Bp = c.L.Bp; p.N = N;
     p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = 3;
     p.op.tr = tr; p.op.tr_ts = (int64_t)N * c.L.Bp; p.op.tr_terms = 3;
     p.flag = flag;
-    hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(N, ldrm), 64), c.L.P), dim3(256), 0, c.s, p);
+    p.colsum_part = colsum;
+    hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(N, ldrm), 64), c.L.P), dim3(64), 0, c.s, p);
     HIPCHK(hipGetLastError());
     return 0;
-}
-
-// column sums of a caller tensor (sum data over the batch, rbm.py:223): reuse `finish` with ks=1
-// on the tensor itself is not possible (it applies bias); a tiny dedicated pass through prep is
-// avoided by letting the FIRST propagation's caller provide them -- see colsum_rows below.
-__global__ __launch_bounds__(256) void colsum_rows(const float* x, int64_t ld, int B, int N, float* part /*[P][N]*/, int P) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= N) return;
-    for (int p = 0; p < P; ++p) {
-        float s = 0.f;
-        for (int i = 0; i < 32; ++i) {
-            const int b = p * 32 + i;
-            if (b < B) s += x[(int64_t)b * ld + col];
-        }
-        part[(int64_t)p * N + col] = s;
-    }
 }
 
 int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms, const int* vpos_flag, int vneg_terms,
@@ -315,11 +300,42 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
     a.vts = (int64_t)L.V * L.Bp; a.hts = (int64_t)L.H * L.Bp; a.Bp = L.Bp;
     a.lr = o->lr; a.mom = o->momentum; a.wd = o->weight_decay; a.n = n;
     a.delta = delta;
-    dim3 grid(cdiv(L.H, 128), cdiv(L.V, 64));
     const bool prof = g_prof.on && !mode_stats && g_prof.used + 2 <= g_prof.ev.size();
     if (prof) HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], c.s));
-    if (mode_stats) hipLaunchKernelGGL(assoc_update<1>, grid, dim3(256), 0, c.s, a);
-    else            hipLaunchKernelGGL(assoc_update<0>, grid, dim3(256), 0, c.s, a);
+    // fast path: every W / W_m / delta row start 16-B aligned -> float4 weight tiles, LDS-staged planes
+    const bool fast = L.H % 4 == 0 && L.H >= 4 && c.d->ldw % 4 == 0 && (((uintptr_t)c.d->W) & 15) == 0 &&
+                      (mode_stats ? ((((uintptr_t)delta) & 15) == 0) : ((((uintptr_t)c.d->W_m) & 15) == 0)) && !g_no_fast_k3;
+    if (fast) {
+        AssocPlanesArgs f;
+        memset(&f, 0, sizeof(f));
+        f.W = a.W; f.Wm = a.Wm; f.ldw = a.ldw; f.V = a.V; f.H = a.H;
+        f.vpos = a.vpos; f.vpos_flag = a.vpos_flag; f.vpos_terms = a.vpos_terms;
+        f.hpos = a.hpos; f.vneg = a.vneg; f.vneg_terms = a.vneg_terms; f.hneg = a.hneg;
+        f.vts = a.vts; f.hts = a.hts; f.Bp = a.Bp;
+        f.lr = a.lr; f.mom = a.mom; f.wd = a.wd; f.n = a.n; f.delta = a.delta;
+        dim3 g(cdiv(L.H, 128), cdiv(L.V, 128));
+#define LAUNCH_K3(M, HTV)                                                                                          \
+    do {                                                                                                           \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            HIPCHK(hipFuncSetAttribute((const void*)assoc_update_planes<M, HTV>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS_BYTES)); \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((assoc_update_planes<M, HTV>), g, dim3(256), K3_LDS_BYTES, c.s, f);                      \
+    } while (0)
+        if (c.rt == 3) { if (mode_stats) LAUNCH_K3(1, 3); else LAUNCH_K3(0, 3); }
+        else           { if (mode_stats) LAUNCH_K3(1, 1); else LAUNCH_K3(0, 1); }
+#undef LAUNCH_K3
+    } else {
+        dim3 grid(cdiv(L.H, 128), cdiv(L.V, 64));
+        if (c.rt == 3) {
+            if (mode_stats) hipLaunchKernelGGL((assoc_update<1, 3>), grid, dim3(256), 0, c.s, a);
+            else            hipLaunchKernelGGL((assoc_update<0, 3>), grid, dim3(256), 0, c.s, a);
+        } else {
+            if (mode_stats) hipLaunchKernelGGL((assoc_update<1, 1>), grid, dim3(256), 0, c.s, a);
+            else            hipLaunchKernelGGL((assoc_update<0, 1>), grid, dim3(256), 0, c.s, a);
+        }
+    }
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], c.s)); g_prof.used += 2; }
     return 0;
@@ -330,9 +346,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o) {
     const Layout& L = c.L;
     const int B = L.B;
     if (o->cd_k < 1) return fail(IMDBN_E_INVALID, "CD=%d (the reference needs CD>=1, rbm.py:204-209)", o->cd_k);
-    CHK(prep(c, data, ldd, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], L.flags));
-    hipLaunchKernelGGL(colsum_rows, dim3(cdiv(L.V, 256)), dim3(256), 0, c.s, data, ldd, B, L.V, L.cs_vpos, L.P);
-    HIPCHK(hipGetLastError());
+    CHK(prep(c, data, ldd, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], L.flags, L.cs_vpos));
     // positive phase: P+ = up(data); h = 1[P+ > U]
     {
         FinishArgs f = new_finish();
@@ -377,7 +391,7 @@ int launch_bias(Ctx& c, const imdbn_cd_opts* o, bool sparsity, float n, float* l
     b.P = L.P; b.lr = o->lr; b.mom = o->momentum; b.n = n;
     b.sparsity = sparsity ? 1 : 0; b.target = o->sparsity_target;
     b.loss_part = L.loss_part; b.n_loss = n_loss_used(c, false); b.loss_den = n * (float)L.V; b.loss_out = loss_out;
-    hipLaunchKernelGGL(bias_update, dim3(cdiv(std::max(L.V, L.H), 256)), dim3(256), 0, c.s, b);
+    hipLaunchKernelGGL(bias_update, dim3(cdiv(std::max(L.V, L.H), 256) + 1), dim3(256), 0, c.s, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -397,13 +411,12 @@ int run_chain(Ctx& c, const float* vk, const float* mask, int64_t ldk, int init_
         if (init_uniform) { p.mix = 1; p.mask = mask; p.ldm = ldk; p.uni = c.rng.floats(B, L.V); }
         p.out_f32 = out; p.ldo = ldo;
         p.op.rm = L.vis_rm[0]; p.op.ldrm = L.Vpad; p.op.rm_ts = (int64_t)L.Bp * L.Vpad; p.op.rm_terms = c.rt;
-        if (want_stats && n_steps == 0) { p.op.tr = L.vis_tr[0]; p.op.tr_ts = (int64_t)L.V * L.Bp; p.op.tr_terms = c.rt; }
-        hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Vpad, 64), L.P), dim3(256), 0, c.s, p);
-        HIPCHK(hipGetLastError());
         if (want_stats && n_steps == 0) {
-            hipLaunchKernelGGL(colsum_rows, dim3(cdiv(L.V, 256)), dim3(256), 0, c.s, out, ldo, B, L.V, L.cs_vpos, L.P);
-            HIPCHK(hipGetLastError());
+            p.op.tr = L.vis_tr[0]; p.op.tr_ts = (int64_t)L.V * L.Bp; p.op.tr_terms = c.rt;
+            p.colsum_part = L.cs_vpos;
         }
+        hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Vpad, 64), L.P), dim3(64), 0, c.s, p);
+        HIPCHK(hipGetLastError());
     }
     for (int t = 0; t < n_steps; ++t) {
         const imdbn_chain_step& s = st[t];
@@ -471,6 +484,15 @@ size_t imdbn_ws_bytes(int V, int H, int B) {
 int imdbn_set_tuning(int ksplit_up, int ksplit_down) {
     g_ks_up = std::max(0, ksplit_up);
     g_ks_down = std::max(0, ksplit_down);
+    return 0;
+}
+
+int imdbn_set_option(const char* name, int value) {
+    if (!name) return fail(IMDBN_E_INVALID, "null option name");
+    if (!strcmp(name, "ksplit_up")) g_ks_up = std::max(0, value);
+    else if (!strcmp(name, "ksplit_down")) g_ks_down = std::max(0, value);
+    else if (!strcmp(name, "generic_k3")) g_no_fast_k3 = value != 0;
+    else return fail(IMDBN_E_INVALID, "unknown option %s", name);
     return 0;
 }
 
@@ -610,7 +632,7 @@ int imdbn_rbm_cd_stats(const imdbn_rbm_desc* d, const float* data, int64_t ldd, 
     p.tail = packed + (size_t)d->V * d->H; p.H = d->H; p.V = d->V;
     p.hpos = c.L.cs_hpos; p.hneg = c.L.cs_hneg; p.vpos = c.L.cs_vpos; p.vneg = c.L.cs_vneg; p.P = c.L.P;
     p.loss_part = c.L.loss_part; p.n_loss = n_loss_used(c, false);
-    hipLaunchKernelGGL(pack_stats, dim3(cdiv(std::max(d->V, d->H), 256)), dim3(256), 0, c.s, p);
+    hipLaunchKernelGGL(pack_stats, dim3(cdiv(std::max(d->V, d->H), 256) + 1), dim3(256), 0, c.s, p);
     HIPCHK(hipGetLastError());
     return 0;
 }

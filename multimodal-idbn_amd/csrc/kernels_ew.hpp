@@ -8,9 +8,10 @@
 //   pack_stats / apply_delta / bias_from_packed   data-parallel split
 //   bernoulli / categorical                       stand-alone sample_visible (rbm.py:118-135)
 //
-// Thread mapping of finish/prep: block = 256 threads = 64 columns x 4 row-quads; a thread owns one
-// column and 8 consecutive batch rows, so fp32 accesses are 256-B row segments per wave and the
-// transposed operand form is one 16-B store per thread.  grid = (ceil(N/64), Bp/32).
+// Thread mapping of finish/prep: block = ONE wave = 64 columns; a thread owns one column and 8
+// consecutive batch rows, so fp32 accesses are 256-B row segments per wave, the transposed operand
+// form is one 16-B store per thread, column sums need no cross-thread step, and the grid
+// (ceil(N/64), Bp/8) has enough blocks to cover the chip even for the 64x1500 hidden side.
 #pragma once
 #include "common.hpp"
 
@@ -73,28 +74,42 @@ __device__ __forceinline__ bool in_group(const FinishArgs& a, int col) {
     return g;
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* sh) {
-    // fixed-order tree: deterministic
-    const int tid = threadIdx.x;
-    sh[tid] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] += sh[tid + s];
-        __syncthreads();
-    }
-    const float r = sh[0];
-    __syncthreads();
-    return r;
+__device__ __forceinline__ float wave_sum(float v) {
+    // fixed butterfly order: deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
 }
 
-__global__ __launch_bounds__(256) void finish(const FinishArgs a) {
-    __shared__ float sh[256];
-    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6;
+__global__ __launch_bounds__(64) void finish(const FinishArgs a) {
+    const int c = threadIdx.x;
     const int col = blockIdx.x * 64 + c;
-    const int b0 = blockIdx.y * 32 + rq * 8;
+    const int b0 = blockIdx.y * 8;
     const bool cok = col < a.N;
     const bool grp = cok && in_group(a, col);
     const float bias = cok ? a.bias[col] : 0.f;
+    float xs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xs[i] = 0.f;
+    if (cok) {
+        // split-K slab sum, k-sequential per element (deterministic); 8 rows x 4 slabs of loads in flight
+        const float* pp = a.partial + (int64_t)b0 * a.N + col;
+        int k = 0;
+        for (; k + 4 <= a.ks; k += 4) {
+            float t[4][8];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[kk][i] = pp[(int64_t)(k + kk) * a.slab + (int64_t)i * a.N];   // rows < Bp always exist
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xs[i] += t[kk][i];
+        }
+        for (; k < a.ks; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xs[i] += pp[(int64_t)k * a.slab + (int64_t)i * a.N];
+    }
     float xp[8], xf[8];
     float csum = 0.f, lsum = 0.f;
 #pragma unroll
@@ -102,10 +117,7 @@ __global__ __launch_bounds__(256) void finish(const FinishArgs a) {
         const int b = b0 + i;
         xp[i] = 0.f; xf[i] = 0.f;
         if (!cok || b >= a.B) continue;
-        float x = 0.f;
-        const float* pp = a.partial + (int64_t)b * a.N + col;
-        for (int k = 0; k < a.ks; ++k) x += pp[k * a.slab];
-        x = x + bias;
+        float x = xs[i] + bias;
         if (a.T != 1.0f) x = x / a.T;
         if (a.sigma > 0.f) x = x + draw_normal(a.noise, b, col) * a.sigma;
         if (a.logits_only || grp) {                 // group columns: softmax etc. in finish_groups
@@ -135,21 +147,14 @@ __global__ __launch_bounds__(256) void finish(const FinishArgs a) {
             lsum += d * d;
         }
     }
-    if (!a.logits_only) {
-        if (!grp) {   // group columns get their operand forms from finish_groups
-            if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
-            if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
-        }
+    if (!a.logits_only && !grp) {   // group columns get their operand forms from finish_groups
+        if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
+        if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
     }
-    if (a.colsum_part) {
-        sh[tid] = csum;
-        __syncthreads();
-        if (rq == 0 && cok) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = ((sh[c] + sh[64 + c]) + sh[128 + c]) + sh[192 + c];
-        __syncthreads();
-    }
+    if (a.colsum_part && cok) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = csum;
     if (a.loss_part) {
-        const float t = block_sum_256(lsum, sh);
-        if (tid == 0) a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+        const float t = wave_sum(lsum);
+        if (c == 0) a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
     }
 }
 
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(64) void finish_groups(const FinishArgs a, int loss
             if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
         }
         if (a.colsum_part) {
-            const int P = a.Bp / 32;
+            const int P = a.Bp / 8;
             a.colsum_part[col] = csum;
             for (int p = 1; p < P; ++p) a.colsum_part[(int64_t)p * a.N + col] = 0.f;
         }
@@ -269,13 +274,15 @@ struct PrepArgs {
     int mix; const float* mask; int64_t ldm; DrawSrc uni;
     float* out_f32; int64_t ldo;
     OperandOut op; int* flag;      // flag |= 1 if any element is not exactly one bf16 term
+    float* colsum_part;            // [Bp/8][N] column sums over each 8-row group (sum data, rbm.py:223)
 };
 
-__global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
-    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6;
+__global__ __launch_bounds__(64) void prep_operand(const PrepArgs a) {
+    const int c = threadIdx.x;
     const int col = blockIdx.x * 64 + c;
-    const int b0 = blockIdx.y * 32 + rq * 8;
+    const int b0 = blockIdx.y * 8;
     float x[8];
+    float csum = 0.f;
     bool inexact = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -289,10 +296,12 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
             }
             if (a.out_f32) a.out_f32[(int64_t)b * a.ldo + col] = v;
             x[i] = v;
+            csum += v;
             inexact |= (__float_as_uint(v) & 0xFFFFu) != 0u;
         }
     }
     if (a.flag && inexact) atomicOr(a.flag, 1);
+    if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = csum;
     store_rm(a.op, x, b0, col);
     store_tr(a.op, x, b0, col, a.N, a.Bp);
 }
@@ -311,7 +320,30 @@ __device__ __forceinline__ float sum_parts(const float* p, int P, int len, int i
     return s;
 }
 
+__device__ __forceinline__ double loss_total_256(const float* part, int n, double* sh) {
+    // thread t sums parts t, t+256, ... in order, then a fixed tree: deterministic
+    const int tid = threadIdx.x;
+    double t = 0.0;
+    for (int k = tid; k < n; k += 256) t += (double)part[k];
+    sh[tid] = t;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) sh[tid] += sh[tid + s2];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+// grid = ceil(max(V,H)/256) + 1: the LAST block only reduces the squared-error partials.
 __global__ __launch_bounds__(256) void bias_update(const BiasArgs a) {
+    __shared__ double sh[256];
+    if (blockIdx.x == gridDim.x - 1) {
+        if (a.loss_out) {
+            const double t = loss_total_256(a.loss_part, a.n_loss, sh);
+            if (threadIdx.x == 0) a.loss_out[0] = (float)(t / (double)a.loss_den);      // rbm.py:226
+        }
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < a.H) {
         const float sp = sum_parts(a.hpos, a.P, a.H, i), sn = sum_parts(a.hneg, a.P, a.H, i);
@@ -328,11 +360,6 @@ __global__ __launch_bounds__(256) void bias_update(const BiasArgs a) {
         a.vb_m[i] = m;
         a.vis_bias[i] += m;
     }
-    if (i == 0 && a.loss_out) {
-        double t = 0.0;
-        for (int k = 0; k < a.n_loss; ++k) t += (double)a.loss_part[k];
-        a.loss_out[0] = (float)(t / (double)a.loss_den);                    // rbm.py:226
-    }
 }
 
 // ---- data-parallel split ------------------------------------------------------------------
@@ -342,6 +369,12 @@ struct PackArgs {
     const float* loss_part; int n_loss;
 };
 __global__ __launch_bounds__(256) void pack_stats(const PackArgs a) {
+    __shared__ double sh[256];
+    if (blockIdx.x == gridDim.x - 1) {
+        const double t = loss_total_256(a.loss_part, a.n_loss, sh);
+        if (threadIdx.x == 0) a.tail[2 * a.H + a.V] = (float)t;
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < a.H) {
         const float sp = sum_parts(a.hpos, a.P, a.H, i), sn = sum_parts(a.hneg, a.P, a.H, i);
@@ -349,11 +382,6 @@ __global__ __launch_bounds__(256) void pack_stats(const PackArgs a) {
         a.tail[a.H + a.V + i] = sp;
     }
     if (i < a.V) a.tail[a.H + i] = sum_parts(a.vpos, a.P, a.V, i) - sum_parts(a.vneg, a.P, a.V, i);
-    if (i == 0) {
-        double t = 0.0;
-        for (int k = 0; k < a.n_loss; ++k) t += (double)a.loss_part[k];
-        a.tail[2 * a.H + a.V] = (float)t;
-    }
 }
 
 struct ApplyArgs {

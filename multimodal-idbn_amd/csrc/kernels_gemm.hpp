@@ -62,116 +62,128 @@ __device__ __forceinline__ void reduce_store_tile(f32x16 (&acc)[2][2], float* __
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: W is [K][N] (N contiguous).  grid = (ceil(N/64), ksplit, Bp/64), block = 256 (4 waves split K).
+// K1 / K2 share one body.  UP: W is [K][N] (N contiguous, B-fragment = 8 dword loads of 128-B row
+// segments).  DOWN: W is [N][K] (K contiguous, B-fragment = two float4 loads per lane).
+// grid = (ceil(N/64), ksplit, Bp/64), block = 256: the 4 waves interleave 16-row K blocks.
+//
+// Pipeline: ALL operands of the next K block (weights and activation fragments) are issued as one
+// group one iteration ahead; the vmcnt counter is in-order, so a wait for a younger activation load
+// would otherwise drain the weight prefetch.  Weight loads are UNCONDITIONAL from clamped addresses
+// (`cond ? load : 0` lowers to one predicated region per load); clamping is harmless because rows
+// k >= K meet zero-padded activation columns and columns n >= N are never stored.
 // ------------------------------------------------------------------------------------------
+template <int NA>
+struct GemmOperands {
+    float wv[2][8];
+    uint4 av[NA][2];
+};
+
+template <bool UP, bool VEC4, int NA>
+__device__ __forceinline__ void gemm_load(GemmOperands<NA>& o, const float* const (&wbase)[2], int64_t ldw, int K,
+                                          const bf16_t* Abase, int64_t a_term_stride, int64_t arow0, int64_t arow1,
+                                          int kb, int hh) {
+    const int k0 = kb + 8 * hh;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        if constexpr (UP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.wv[nt][j] = wbase[nt][(int64_t)min(k0 + j, K - 1) * ldw];
+        } else if constexpr (VEC4) {      // K % 4 == 0 here: a float4 is either fully inside or fully outside
+            const float4 x0 = *reinterpret_cast<const float4*>(wbase[nt] + min(k0, K - 4));
+            const float4 x1 = *reinterpret_cast<const float4*>(wbase[nt] + min(k0 + 4, K - 4));
+            o.wv[nt][0] = x0.x; o.wv[nt][1] = x0.y; o.wv[nt][2] = x0.z; o.wv[nt][3] = x0.w;
+            o.wv[nt][4] = x1.x; o.wv[nt][5] = x1.y; o.wv[nt][6] = x1.z; o.wv[nt][7] = x1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.wv[nt][j] = wbase[nt][min(k0 + j, K - 1)];
+        }
+    }
+#pragma unroll
+    for (int ta = 0; ta < NA; ++ta) {
+        o.av[ta][0] = *reinterpret_cast<const uint4*>(Abase + ta * a_term_stride + arow0 + k0);
+        o.av[ta][1] = *reinterpret_cast<const uint4*>(Abase + ta * a_term_stride + arow1 + k0);
+    }
+}
+
+template <bool UP, int NW, bool VEC4, int NA>
+__device__ __forceinline__ void gemm_body(const float* __restrict__ W, int64_t ldw, int K, int N,
+                                          const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
+                                          float* __restrict__ partial, int Bp, int kchunk, float (*red)[2][16][64]) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int n0 = blockIdx.x * 64, ks = blockIdx.y, mb = blockIdx.z * 64;
+    const int k_begin = ks * kchunk;
+    const int k_end = min(k_begin + kchunk, lda);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    const float* wbase[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = min(n0 + nt * 32 + r, N - 1);
+        wbase[nt] = UP ? (W + n) : (W + (int64_t)n * ldw);
+    }
+    const int64_t arow0 = (int64_t)(mb + r) * lda, arow1 = (int64_t)(mb + 32 + r) * lda;
+
+    auto compute = [&](const GemmOperands<NA>& o) {
+        uint4 bf[2][NW];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) make_w_frags<NW>(o.wv[nt], bf[nt]);
+#pragma unroll
+        for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int tw = 0; tw < NW; ++tw)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(o.av[ta][mt]), as_frag(bf[nt][tw]), acc[mt][nt], 0, 0, 0);
+    };
+    // ping-pong operand buffers (no register copies: a copy would wait for the prefetch it copies)
+    const int kb0 = k_begin + 16 * w;
+    GemmOperands<NA> oa, ob;
+    if (kb0 < k_end) gemm_load<UP, VEC4, NA>(oa, wbase, ldw, K, A, a_term_stride, arow0, arow1, kb0, hh);
+    for (int kb = kb0; kb < k_end; kb += 128) {
+        gemm_load<UP, VEC4, NA>(ob, wbase, ldw, K, A, a_term_stride, arow0, arow1, min(kb + 64, lda - 16), hh);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(oa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 64 >= k_end) break;
+        gemm_load<UP, VEC4, NA>(oa, wbase, ldw, K, A, a_term_stride, arow0, arow1, min(kb + 128, lda - 16), hh);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(ob);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    reduce_store_tile(acc, partial + (int64_t)ks * Bp * N, N, mb, n0, red);
+}
+
+// The activation term count (1 for {0,1} samples / exactly-bf16 data, 3 otherwise) is a wave-uniform
+// run-time value (flag in device memory for caller data): dispatch once to a fully static body.
 template <int NW>
 __global__ __launch_bounds__(256) void gemm_up_partial(
     const float* __restrict__ W, int64_t ldw, int K, int N,
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
     float* __restrict__ partial, int Bp, int kchunk) {
     __shared__ float red[4][2][16][64];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int n0 = blockIdx.x * 64, ks = blockIdx.y, mb = blockIdx.z * 64;
-    const int k_begin = ks * kchunk;
-    const int k_end = min(k_begin + kchunk, lda);
     const int na = a_terms ? a_terms : (*a_flag ? 3 : 1);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-
-    for (int kb = k_begin + 16 * w; kb < k_end; kb += 64) {
-        float wv[2][8];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + nt * 32 + r;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = kb + 8 * hh + j;
-                wv[nt][j] = (k < K && n < N) ? W[(int64_t)k * ldw + n] : 0.f;
-            }
-        }
-        uint4 bf[2][NW];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) make_w_frags<NW>(wv[nt], bf[nt]);
-        for (int ta = 0; ta < na; ++ta) {
-            const bf16_t* Ap = A + ta * a_term_stride + kb + 8 * hh;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const uint4 av = *reinterpret_cast<const uint4*>(Ap + (int64_t)(mb + mt * 32 + r) * lda);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int tw = 0; tw < NW; ++tw)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(av), as_frag(bf[nt][tw]), acc[mt][nt], 0, 0, 0);
-            }
-        }
-    }
-    reduce_store_tile(acc, partial + (int64_t)ks * Bp * N, N, mb, n0, red);
+    if (na == 1) gemm_body<true, NW, false, 1>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
+    else         gemm_body<true, NW, false, 3>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
 }
 
-// ------------------------------------------------------------------------------------------
-// K2: W is [N][K] (K contiguous).  Same grid shape with N = V, K = H.
-// ------------------------------------------------------------------------------------------
 template <int NW, bool VEC4>
 __global__ __launch_bounds__(256) void gemm_down_partial(
     const float* __restrict__ W, int64_t ldw, int K, int N,
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
     float* __restrict__ partial, int Bp, int kchunk) {
     __shared__ float red[4][2][16][64];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int n0 = blockIdx.x * 64, ks = blockIdx.y, mb = blockIdx.z * 64;
-    const int k_begin = ks * kchunk;
-    const int k_end = min(k_begin + kchunk, lda);
     const int na = a_terms ? a_terms : (*a_flag ? 3 : 1);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-
-    for (int kb = k_begin + 16 * w; kb < k_end; kb += 64) {
-        float wv[2][8];
-        const int k0 = kb + 8 * hh;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + nt * 32 + r;
-            const float* wp = W + (int64_t)n * ldw + k0;
-            if constexpr (VEC4) {
-                float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-                if (n < N && k0 + 3 < K) x0 = *reinterpret_cast<const float4*>(wp);
-                if (n < N && k0 + 7 < K) x1 = *reinterpret_cast<const float4*>(wp + 4);
-                wv[nt][0] = x0.x; wv[nt][1] = x0.y; wv[nt][2] = x0.z; wv[nt][3] = x0.w;
-                wv[nt][4] = x1.x; wv[nt][5] = x1.y; wv[nt][6] = x1.z; wv[nt][7] = x1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) wv[nt][j] = (n < N && k0 + j < K) ? wp[j] : 0.f;
-            }
-        }
-        uint4 bf[2][NW];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) make_w_frags<NW>(wv[nt], bf[nt]);
-        for (int ta = 0; ta < na; ++ta) {
-            const bf16_t* Ap = A + ta * a_term_stride + k0;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const uint4 av = *reinterpret_cast<const uint4*>(Ap + (int64_t)(mb + mt * 32 + r) * lda);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int tw = 0; tw < NW; ++tw)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(av), as_frag(bf[nt][tw]), acc[mt][nt], 0, 0, 0);
-            }
-        }
-    }
-    reduce_store_tile(acc, partial + (int64_t)ks * Bp * N, N, mb, n0, red);
+    if (na == 1) gemm_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
+    else         gemm_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -191,46 +203,93 @@ struct AssocArgs {
     float* delta;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void assoc_update(const AssocArgs a) {
+// All operand fragments of one 16-row batch block for this wave's 32(v) x 64(h) tile.
+template <int HT, int NAP, int NAN_>
+struct AssocFrags {
+    uint4 bp[2][HT], bn[2][HT], ap[NAP], an[NAN_];
+};
+
+template <int HT, int NAP, int NAN_>
+__device__ __forceinline__ void assoc_load(AssocFrags<HT, NAP, NAN_>& f, const AssocArgs& a, int kb, int64_t vrow,
+                                           int64_t hrow0, int64_t hrow1) {
+    // rows are clamped by the caller (never predicated): out-of-range rows only feed outputs that are not stored
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        f.bp[0][t] = *reinterpret_cast<const uint4*>(a.hpos + t * a.hts + hrow0 + kb);
+        f.bp[1][t] = *reinterpret_cast<const uint4*>(a.hpos + t * a.hts + hrow1 + kb);
+        f.bn[0][t] = *reinterpret_cast<const uint4*>(a.hneg + t * a.hts + hrow0 + kb);
+        f.bn[1][t] = *reinterpret_cast<const uint4*>(a.hneg + t * a.hts + hrow1 + kb);
+    }
+#pragma unroll
+    for (int t = 0; t < NAP; ++t) f.ap[t] = *reinterpret_cast<const uint4*>(a.vpos + t * a.vts + vrow + kb);
+#pragma unroll
+    for (int t = 0; t < NAN_; ++t) {
+        uint4 x = *reinterpret_cast<const uint4*>(a.vneg + t * a.vts + vrow + kb);
+        // negate the 8 bf16 values: acc accumulates X^T P+ - V'^T P- in one accumulator
+        x.x ^= 0x80008000u; x.y ^= 0x80008000u; x.z ^= 0x80008000u; x.w ^= 0x80008000u;
+        f.an[t] = x;
+    }
+}
+
+template <int MODE, int HT, int NAP, int NAN_>
+__device__ __forceinline__ void assoc_body(const AssocArgs& a) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
     const int v0 = blockIdx.y * 64 + (w >> 1) * 32;
     const int h0 = blockIdx.x * 128 + (w & 1) * 64;
-    const int nap = a.vpos_terms ? a.vpos_terms : (*a.vpos_flag ? 3 : 1);
-    const int nan_ = a.vneg_terms ? a.vneg_terms : (*a.vneg_flag ? 3 : 1);
-    const bool vok = (v0 + r) < a.V;
-    const bool hok0 = (h0 + r) < a.H, hok1 = (h0 + 32 + r) < a.H;
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    const int64_t vrow = (int64_t)min(v0 + r, a.V - 1) * a.Bp + 8 * hh;
+    const int64_t hrow0 = (int64_t)min(h0 + r, a.H - 1) * a.Bp + 8 * hh;
+    const int64_t hrow1 = (int64_t)min(h0 + 32 + r, a.H - 1) * a.Bp + 8 * hh;
 
-    f32x16 accp[2], accn[2];
+    AssocFrags<HT, NAP, NAN_> cur, nxt;
+    assoc_load(cur, a, 0, vrow, hrow0, hrow1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Prefetch this wave's W / W_m tile (C layout: per (nt,reg) two 128-B row segments per wave): all 64
+    // loads are in flight together, their HBM latency hides under the operand loads + MFMAs.
+    float wold[2][16], mold[2][16];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = min(h0 + nt * 32 + r, a.H - 1);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t idx = (int64_t)min(v0 + mfma_row(reg, l), a.V - 1) * a.ldw + col;
+                wold[nt][reg] = a.W[idx];
+                mold[nt][reg] = a.Wm[idx];
+            }
+        }
+    }
+
+    f32x16 acc[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { accp[nt][i] = 0.f; accn[nt][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
-    const int64_t vrow = (int64_t)(v0 + r) * a.Bp + 8 * hh;
-    const int64_t hrow0 = (int64_t)(h0 + r) * a.Bp + 8 * hh;
-    const int64_t hrow1 = (int64_t)(h0 + 32 + r) * a.Bp + 8 * hh;
-
-    for (int kb = 0; kb < a.Bp; kb += 16) {
-        for (int tb = 0; tb < a.hpos_terms; ++tb) {
-            const uint4 b0 = hok0 ? *reinterpret_cast<const uint4*>(a.hpos + tb * a.hts + hrow0 + kb) : z4;
-            const uint4 b1 = hok1 ? *reinterpret_cast<const uint4*>(a.hpos + tb * a.hts + hrow1 + kb) : z4;
-            for (int ta = 0; ta < nap; ++ta) {
-                const uint4 av = vok ? *reinterpret_cast<const uint4*>(a.vpos + ta * a.vts + vrow + kb) : z4;
-                accp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(av), as_frag(b0), accp[0], 0, 0, 0);
-                accp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(av), as_frag(b1), accp[1], 0, 0, 0);
+    auto compute = [&](const AssocFrags<HT, NAP, NAN_>& f) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int tb = 0; tb < HT; ++tb) {
+#pragma unroll
+                for (int ta = 0; ta < NAP; ++ta)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(f.ap[ta]), as_frag(f.bp[nt][tb]), acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int ta = 0; ta < NAN_; ++ta)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(f.an[ta]), as_frag(f.bn[nt][tb]), acc[nt], 0, 0, 0);
             }
         }
-        for (int tb = 0; tb < a.hneg_terms; ++tb) {
-            const uint4 b0 = hok0 ? *reinterpret_cast<const uint4*>(a.hneg + tb * a.hts + hrow0 + kb) : z4;
-            const uint4 b1 = hok1 ? *reinterpret_cast<const uint4*>(a.hneg + tb * a.hts + hrow1 + kb) : z4;
-            for (int ta = 0; ta < nan_; ++ta) {
-                const uint4 av = vok ? *reinterpret_cast<const uint4*>(a.vneg + ta * a.vts + vrow + kb) : z4;
-                accn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(av), as_frag(b0), accn[0], 0, 0, 0);
-                accn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(av), as_frag(b1), accn[1], 0, 0, 0);
-            }
-        }
+    };
+    // Bp is a multiple of 64: an even number of 16-row blocks, processed ping-pong (no register copies)
+    for (int kb = 0; kb < a.Bp; kb += 32) {
+        assoc_load(nxt, a, kb + 16, vrow, hrow0, hrow1);
+        __builtin_amdgcn_sched_barrier(0);      // keep the load group ahead of (not interleaved with) the MFMAs
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        assoc_load(cur, a, min(kb + 32, a.Bp - 16), vrow, hrow0, hrow1);      // redundant on the last pair
+        __builtin_amdgcn_sched_barrier(0);
+        compute(nxt);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #pragma unroll
@@ -240,19 +299,183 @@ __global__ __launch_bounds__(256) void assoc_update(const AssocArgs a) {
         for (int reg = 0; reg < 16; ++reg) {
             const int row = v0 + mfma_row(reg, l);
             if (row < a.V && col < a.H) {
-                const float d = accp[nt][reg] - accn[nt][reg];                  // pos_assoc - neg_assoc
+                const float d = acc[nt][reg];                                     // pos_assoc - neg_assoc
                 if constexpr (MODE == 0) {
                     const int64_t idx = (int64_t)row * a.ldw + col;
-                    const float wold = a.W[idx];
-                    float m = a.Wm[idx];
-                    const float g = d / a.n - a.wd * wold;                        // rbm.py:212
+                    const float w0 = wold[nt][reg];
+                    float m = mold[nt][reg];
+                    const float g = d / a.n - a.wd * w0;                          // rbm.py:212
                     m = m * a.mom;
                     m = m + a.lr * g;
                     a.Wm[idx] = m;
-                    a.W[idx] = wold + m;                                          // rbm.py:213
+                    a.W[idx] = w0 + m;                                            // rbm.py:213
                 } else {
                     a.delta[(int64_t)row * a.H + col] = d;
                 }
+            }
+        }
+    }
+}
+
+// HT = terms of the hidden-side operands (3 parity / 1 fast).  The visible-side term counts (1 for
+// {0,1} samples or exactly-bf16 data, 3 otherwise) are wave-uniform run-time values: dispatch once to a
+// fully static body so every fragment load can be issued ahead of its MFMAs.
+template <int MODE, int HT>
+__global__ __launch_bounds__(256) void assoc_update(const AssocArgs a) {
+    const int nap = a.vpos_terms ? a.vpos_terms : (*a.vpos_flag ? 3 : 1);
+    const int nan_ = a.vneg_terms ? a.vneg_terms : (*a.vneg_flag ? 3 : 1);
+    if (nap == 1) {
+        if (nan_ == 1) assoc_body<MODE, HT, 1, 1>(a);
+        else           assoc_body<MODE, HT, 1, 3>(a);
+    } else {
+        if (nan_ == 1) assoc_body<MODE, HT, 3, 1>(a);
+        else           assoc_body<MODE, HT, 3, 3>(a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3, fast path (W rows 16-B aligned): bf16 operand planes staged through LDS, float4 weight tiles.
+//
+//   * Weight traffic is the whole cost (read + write W and W_m = 16 B per element), so the tile is
+//     shaped for it: a wave owns 32(v) x 128(h) as FOUR INTERLEAVED 32x32 MFMA tiles
+//     (column of tile t, lane r = h0 + 4r + t), i.e. one float4 per lane per accumulator row ->
+//     512-B contiguous row segments per half-wave (measured 1.3-1.5x the dword shape, tools/membench).
+//     All 32 float4 loads (W, W_m) are issued at kernel entry and land under the staging + MFMAs.
+//   * The operands are the pre-split transposed bf16 planes written by finish/prep
+//     (tr[t][feature][Bp], 8 batch rows = 16 B).  K = batch is tiny (64 per chunk), so a block copies
+//     the planes of its 128 hidden and 128 visible features into LDS with plain coalesced 16-B
+//     copies; every fragment is then ONE ds_read_b128 with no VALU work in the MFMA loop.  LDS rows
+//     are padded to 144 B and hidden rows are stored permuted (feature 4r+t at row t*32+r) so that
+//     consecutive lanes read consecutive rows: (9*row + chunk) mod 16 is a bijection -> conflict-free.
+//   * History (profiles/r01_*): fragment loads straight from global were L2-latency bound (98 us);
+//     an fp32-MFMA variant was matrix-pipe bound (91 us); fp32 in LDS + in-register splitting was
+//     VALU bound at one wave per SIMD (75 us).
+// grid = (ceil(H/128), ceil(V/128)), block = 256 (wave w: rows v0+32w..+31), 144 KB dynamic LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int K3_ROWB = 144;                 // padded LDS row: 64 bf16 = 128 B + 16 B
+constexpr int K3_PLANE = 128 * K3_ROWB;      // one plane of 128 features
+constexpr int K3_LDS_BYTES = 8 * K3_PLANE;   // 6 hidden planes (pos/neg x 3 terms) + 2 visible planes (or time-shared)
+
+struct AssocPlanesArgs {
+    float* W; float* Wm; int64_t ldw; int V, H;
+    const bf16_t* vpos; const int* vpos_flag; int vpos_terms;
+    const bf16_t* hpos;
+    const bf16_t* vneg; int vneg_terms;
+    const bf16_t* hneg;
+    int64_t vts, hts; int Bp;
+    float lr, mom, wd, n;
+    float* delta;
+};
+
+// copy `nplanes` planes of 128 features x 64 batch rows (chunk b0) into LDS; PERM: hidden-side row permutation
+template <bool PERM>
+__device__ __forceinline__ void k3_stage(char* dst, const bf16_t* src, int64_t term_stride, int nplanes, int f0, int F,
+                                         int Bp, int b0, bool negate) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nplanes * 1024; i += 256) {          // 1024 16-B chunks per plane
+        const int pl = i >> 10, row = (i >> 3) & 127, c = i & 7;
+        const int f = min(f0 + row, F - 1);
+        uint4 x = *reinterpret_cast<const uint4*>(src + pl * term_stride + (int64_t)f * Bp + b0 + 8 * c);
+        if (negate) { x.x ^= 0x80008000u; x.y ^= 0x80008000u; x.z ^= 0x80008000u; x.w ^= 0x80008000u; }
+        const int lrow = PERM ? ((row & 3) * 32 + (row >> 2)) : row;
+        *reinterpret_cast<uint4*>(dst + pl * K3_PLANE + lrow * K3_ROWB + 16 * c) = x;
+    }
+}
+
+template <int HT, int NA>
+__device__ __forceinline__ void k3_mfma(f32x16 (&acc)[4], const char* sH, const char* sV, int w, int r, int kh) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        uint4 af[NA];
+#pragma unroll
+        for (int ta = 0; ta < NA; ++ta)
+            af[ta] = *reinterpret_cast<const uint4*>(sV + ta * K3_PLANE + (32 * w + r) * K3_ROWB + 32 * kb + 16 * kh);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int tb = 0; tb < HT; ++tb) {
+                const uint4 bf = *reinterpret_cast<const uint4*>(sH + tb * K3_PLANE + (t * 32 + r) * K3_ROWB + 32 * kb + 16 * kh);
+#pragma unroll
+                for (int ta = 0; ta < NA; ++ta)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[ta]), as_frag(bf), acc[t], 0, 0, 0);
+            }
+    }
+}
+
+template <int MODE, int HT>
+__global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, kh = l >> 5;
+    const int h0 = blockIdx.x * 128, v0 = blockIdx.y * 128;
+    const int vw = v0 + 32 * w;
+    const int nap = a.vpos_terms ? a.vpos_terms : (*a.vpos_flag ? 3 : 1);
+    const int nan_ = a.vneg_terms;
+
+    float4 wold[16], mold[16];
+    const int colc = min(h0 + 4 * r, a.H - 4);
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t idx = (int64_t)min(vw + mfma_row(reg, l), a.V - 1) * a.ldw + colc;
+            wold[reg] = *reinterpret_cast<const float4*>(a.W + idx);
+            mold[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
+        }
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    char* sHp = smem;                       // HT planes
+    char* sHn = smem + 3 * K3_PLANE;        // HT planes
+    char* sVa = smem + 6 * K3_PLANE;        // visible planes: pos then neg when both are single-term,
+    char* sVb = smem + 7 * K3_PLANE;        // otherwise the 2 planes + the free hidden slots are time-shared
+    const bool both = (nap == 1 && nan_ == 1);
+    for (int b0 = 0; b0 < a.Bp; b0 += 64) {
+        __syncthreads();
+        if (both) {
+            // everything of this chunk fits: one staging pass, one barrier, 8 MFMA k-blocks back to back
+            k3_stage<true>(sHp, a.hpos, a.hts, HT, h0, a.H, a.Bp, b0, false);
+            k3_stage<true>(sHn, a.hneg, a.hts, HT, h0, a.H, a.Bp, b0, false);
+            k3_stage<false>(sVa, a.vpos, a.vts, 1, v0, a.V, a.Bp, b0, false);
+            k3_stage<false>(sVb, a.vneg, a.vts, 1, v0, a.V, a.Bp, b0, true);
+            __syncthreads();
+            k3_mfma<HT, 1>(acc, sHp, sVa, w, r, kh);
+            k3_mfma<HT, 1>(acc, sHn, sVb, w, r, kh);
+        } else {
+            // real-valued visible activations (3 terms): positive and negative phase time-share the LDS
+            k3_stage<true>(sHp, a.hpos, a.hts, HT, h0, a.H, a.Bp, b0, false);
+            k3_stage<false>(sHn, a.vpos, a.vts, nap, v0, a.V, a.Bp, b0, false);
+            __syncthreads();
+            if (nap == 1) k3_mfma<HT, 1>(acc, sHp, sHn, w, r, kh); else k3_mfma<HT, 3>(acc, sHp, sHn, w, r, kh);
+            __syncthreads();
+            k3_stage<true>(sHp, a.hneg, a.hts, HT, h0, a.H, a.Bp, b0, false);
+            k3_stage<false>(sHn, a.vneg, a.vts, nan_, v0, a.V, a.Bp, b0, true);
+            __syncthreads();
+            if (nan_ == 1) k3_mfma<HT, 1>(acc, sHp, sHn, w, r, kh); else k3_mfma<HT, 3>(acc, sHp, sHn, w, r, kh);
+        }
+    }
+
+    const bool cok = (h0 + 4 * r) < a.H;          // H % 4 == 0: a float4 is entirely inside or outside
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = vw + mfma_row(reg, l);
+        if (row < a.V && cok) {
+            const float4 d = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);   // pos_assoc - neg_assoc
+            if constexpr (MODE == 0) {
+                const int64_t idx = (int64_t)row * a.ldw + h0 + 4 * r;
+                const float4 w0 = wold[reg];
+                float4 m = mold[reg];
+                m.x = m.x * a.mom; m.x = m.x + a.lr * (d.x / a.n - a.wd * w0.x);        // rbm.py:212
+                m.y = m.y * a.mom; m.y = m.y + a.lr * (d.y / a.n - a.wd * w0.y);
+                m.z = m.z * a.mom; m.z = m.z + a.lr * (d.z / a.n - a.wd * w0.z);
+                m.w = m.w * a.mom; m.w = m.w + a.lr * (d.w / a.n - a.wd * w0.w);
+                *reinterpret_cast<float4*>(a.Wm + idx) = m;
+                *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
+            } else {
+                *reinterpret_cast<float4*>(a.delta + (int64_t)row * a.H + h0 + 4 * r) = d;
             }
         }
     }

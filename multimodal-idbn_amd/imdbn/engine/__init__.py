@@ -39,7 +39,7 @@ def get_engine(t: torch.Tensor):
     return _hip
 
 
-def hip_engine():
+def get_hip_engine():
     """The process-wide HipEngine (loads the native library; raises if it is not built)."""
     global _hip
     if _hip is None:
@@ -76,5 +76,5 @@ def use_rng(rng):
         _rng = old
 
 
-__all__ = ["get_engine", "hip_engine", "set_engine_for_testing", "get_rng", "set_rng", "manual_seed", "use_rng",
+__all__ = ["get_engine", "get_hip_engine", "set_engine_for_testing", "get_rng", "set_rng", "manual_seed", "use_rng",
            "PhiloxRng", "ReplayRng", "EngineError", "dp"]

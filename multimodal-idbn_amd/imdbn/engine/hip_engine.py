@@ -49,6 +49,10 @@ class HipEngine:
         N.check(self._lib.imdbn_set_tuning(int(ksplit_up), int(ksplit_down)), "imdbn_set_tuning")
         self._ws.clear()
 
+    def set_option(self, name: str, value: int):
+        N.check(self._lib.imdbn_set_option(name.encode(), int(value)), "imdbn_set_option")
+        self._ws.clear()
+
     def profile(self, on: bool):
         N.check(self._lib.imdbn_profile_enable(1 if on else 0), "imdbn_profile_enable")
 

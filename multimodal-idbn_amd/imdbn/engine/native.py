@@ -61,6 +61,7 @@ SIGNATURES = {
     "imdbn_device_info": (_INT, [C.POINTER(_INT), C.c_char_p, _SZ]),
     "imdbn_ws_bytes": (_SZ, [_INT, _INT, _INT]),
     "imdbn_set_tuning": (_INT, [_INT, _INT]),
+    "imdbn_set_option": (_INT, [C.c_char_p, _INT]),
     "imdbn_profile_enable": (_INT, [_INT]),
     "imdbn_profile_read": (_INT, [C.POINTER(C.c_double), C.POINTER(_INT)]),
     "imdbn_rbm_prop_up": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _F, C.POINTER(Rng), _P, _I64, _P, _I64, _P, _SZ, _P]),

@@ -24,7 +24,7 @@ def _native():
     ge.build()
     from imdbn import engine as E
     E.set_engine_for_testing(None)
-    eng = E.hip_engine()             # raises if the library is missing: no silent fallback
+    eng = E.get_hip_engine()             # raises if the library is missing: no silent fallback
     cu, arch = eng.device_info()
     assert "gfx950" in arch, arch
     yield eng
@@ -163,7 +163,7 @@ def test_full_size_properties():
     g = np.random.Generator(np.random.PCG64(1))
     W0 = (g.standard_normal((Vv, Hh), dtype=F32) * F32(0.01)).astype(F32)
     X = (g.random((B, Vv), dtype=F32) > 0.9).astype(F32)
-    eng = E.hip_engine()
+    eng = E.get_hip_engine()
 
     def fresh():
         r = RBM(Vv, Hh, 0.1, 1e-4, 0.5)

@@ -9,3 +9,6 @@ echo "pytest exit $?" | tee -a gpurun_out/pytest_gpu.log
 tail -40 gpurun_out/pytest_gpu.log
 timeout -k 10 120 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -3 gpurun_out/smoke.log
 timeout -k 10 200 python bench.py --steps 200 --warmup 20 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -2 gpurun_out/bench.log
+# kernel trace of the same bench command (summary copied to profiles/ by hand)
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; echo "rocprof exit $?"
+cd $GRAFT_REPO_ROOT; find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -20

@@ -303,7 +303,7 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
     const bool prof = g_prof.on && !mode_stats && g_prof.used + 2 <= g_prof.ev.size();
     if (prof) HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], c.s));
     // fast path: every W / W_m / delta row start 16-B aligned -> float4 weight tiles, LDS-staged planes
-    const bool fast = L.H % 4 == 0 && L.H >= 4 && c.d->ldw % 4 == 0 && (((uintptr_t)c.d->W) & 15) == 0 &&
+    const bool fast = L.Bp == 64 && L.H % 4 == 0 && L.H >= 4 && c.d->ldw % 4 == 0 && (((uintptr_t)c.d->W) & 15) == 0 &&
                       (mode_stats ? ((((uintptr_t)delta) & 15) == 0) : ((((uintptr_t)c.d->W_m) & 15) == 0)) && !g_no_fast_k3;
     if (fast) {
         AssocPlanesArgs f;
@@ -313,16 +313,13 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
         f.hpos = a.hpos; f.vneg = a.vneg; f.vneg_terms = a.vneg_terms; f.hneg = a.hneg;
         f.vts = a.vts; f.hts = a.hts; f.Bp = a.Bp;
         f.lr = a.lr; f.mom = a.mom; f.wd = a.wd; f.n = a.n; f.delta = a.delta;
-        dim3 g(cdiv(L.H, 128), cdiv(L.V, 128));
-#define LAUNCH_K3(M, HTV)                                                                                          \
-    do {                                                                                                           \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
-            HIPCHK(hipFuncSetAttribute((const void*)assoc_update_planes<M, HTV>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS_BYTES)); \
-            attr_set = true;                                                                                       \
-        }                                                                                                          \
-        hipLaunchKernelGGL((assoc_update_planes<M, HTV>), g, dim3(256), K3_LDS_BYTES, c.s, f);                      \
-    } while (0)
+        // ~one block per CU: each block streams `tpb` visible tiles with its hidden planes resident in LDS
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int nh = cdiv(L.H, 128), nv = cdiv(L.V, 128);
+        const int tpb = std::max(1, cdiv(nh * nv, std::max(cus, 1)));
+        dim3 g(nh, cdiv(nv, tpb));
+#define LAUNCH_K3(M, HTV) hipLaunchKernelGGL((assoc_update_planes<M, HTV>), g, dim3(256), 0, c.s, f, tpb)
         if (c.rt == 3) { if (mode_stats) LAUNCH_K3(1, 3); else LAUNCH_K3(0, 3); }
         else           { if (mode_stats) LAUNCH_K3(1, 1); else LAUNCH_K3(0, 1); }
 #undef LAUNCH_K3

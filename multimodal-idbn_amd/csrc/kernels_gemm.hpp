@@ -144,20 +144,16 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ W, int64_t l
                     for (int tw = 0; tw < NW; ++tw)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(o.av[ta][mt]), as_frag(bf[nt][tw]), acc[mt][nt], 0, 0, 0);
     };
-    // ping-pong operand buffers (no register copies: a copy would wait for the prefetch it copies)
     const int kb0 = k_begin + 16 * w;
-    GemmOperands<NA> oa, ob;
-    if (kb0 < k_end) gemm_load<UP, VEC4, NA>(oa, wbase, ldw, K, A, a_term_stride, arow0, arow1, kb0, hh);
-    for (int kb = kb0; kb < k_end; kb += 128) {
-        gemm_load<UP, VEC4, NA>(ob, wbase, ldw, K, A, a_term_stride, arow0, arow1, min(kb + 64, lda - 16), hh);
+    GemmOperands<NA> cur, nxt;
+    if (kb0 < k_end) gemm_load<UP, VEC4, NA>(cur, wbase, ldw, K, A, a_term_stride, arow0, arow1, kb0, hh);
+    for (int kb = kb0; kb < k_end; kb += 64) {
+        // next block's operands: one load group, pinned ahead of this block's math
+        gemm_load<UP, VEC4, NA>(nxt, wbase, ldw, K, A, a_term_stride, arow0, arow1, min(kb + 64, lda - 16), hh);
         __builtin_amdgcn_sched_barrier(0);
-        compute(oa);
+        compute(cur);
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + 64 >= k_end) break;
-        gemm_load<UP, VEC4, NA>(oa, wbase, ldw, K, A, a_term_stride, arow0, arow1, min(kb + 128, lda - 16), hh);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(ob);
-        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
     reduce_store_tile(acc, partial + (int64_t)ks * Bp * N, N, mb, n0, red);
 }
@@ -367,19 +363,32 @@ struct AssocPlanesArgs {
     float* delta;
 };
 
-// copy `nplanes` planes of 128 features x 64 batch rows (chunk b0) into LDS; PERM: hidden-side row permutation
-template <bool PERM>
-__device__ __forceinline__ void k3_stage(char* dst, const bf16_t* src, int64_t term_stride, int nplanes, int f0, int F,
+// copy `nplanes` planes of 128 features x 64 batch rows (chunk b0) into LDS; PERM: hidden-side row permutation.
+// Per plane a thread moves 4 of the 1024 16-B chunks; the loads of a plane pair are issued as one batch
+// (a load->store loop would serialise one L2 round trip per chunk).
+template <bool PERM, int NPL>
+__device__ __forceinline__ void k3_stage(char* dst, const bf16_t* src, int64_t term_stride, int f0, int F,
                                          int Bp, int b0, bool negate) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < nplanes * 1024; i += 256) {          // 1024 16-B chunks per plane
-        const int pl = i >> 10, row = (i >> 3) & 127, c = i & 7;
-        const int f = min(f0 + row, F - 1);
-        uint4 x = *reinterpret_cast<const uint4*>(src + pl * term_stride + (int64_t)f * Bp + b0 + 8 * c);
-        if (negate) { x.x ^= 0x80008000u; x.y ^= 0x80008000u; x.z ^= 0x80008000u; x.w ^= 0x80008000u; }
-        const int lrow = PERM ? ((row & 3) * 32 + (row >> 2)) : row;
-        *reinterpret_cast<uint4*>(dst + pl * K3_PLANE + lrow * K3_ROWB + 16 * c) = x;
-    }
+    uint4 x[NPL][4];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q, row = i >> 3, c = i & 7;
+            x[pl][q] = *reinterpret_cast<const uint4*>(src + pl * term_stride + (int64_t)min(f0 + row, F - 1) * Bp + b0 + 8 * c);
+        }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q, row = i >> 3, c = i & 7;
+            uint4 v = x[pl][q];
+            if (negate) { v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u; }
+            const int lrow = PERM ? ((row & 3) * 32 + (row >> 2)) : row;
+            *reinterpret_cast<uint4*>(dst + pl * K3_PLANE + lrow * K3_ROWB + 16 * c) = v;
+        }
+    __builtin_amdgcn_sched_barrier(0);     // keep the batches apart: at most NPL*4 staging registers live at once
 }
 
 template <int HT, int NA>
@@ -402,82 +411,91 @@ __device__ __forceinline__ void k3_mfma(f32x16 (&acc)[4], const char* sH, const 
     }
 }
 
+// Streaming form: block (bx, by) owns hidden columns [128*bx, +128) and the `tiles_per_block` visible
+// tiles starting at tile by*tiles_per_block.  The hidden planes (pos+neg, HT terms: up to 108 KB) are
+// staged ONCE and stay in LDS; per visible tile only one 18-KB visible plane per term is re-staged
+// (two buffers alternate -> one barrier per plane), and the float4 W / W_m tile of the NEXT visible
+// tile is prefetched into a second register set while the current tile runs its MFMAs + epilogue
+// (one wave per SIMD, 512 registers).  Operand re-reads drop from ~120 MB to ~50 MB per launch and
+// the weight stream never waits on a dependent load.
+// Requires Bp == 64 (one batch chunk) and 16-B aligned weight rows; otherwise the generic kernel runs.
 template <int MODE, int HT>
-__global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block) {
+    __shared__ __attribute__((aligned(16))) char smem[K3_LDS_BYTES];      // 144 KB static (the CU has 160 KB)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, kh = l >> 5;
-    const int h0 = blockIdx.x * 128, v0 = blockIdx.y * 128;
-    const int vw = v0 + 32 * w;
+    const int h0 = blockIdx.x * 128;
+    const int tile0 = blockIdx.y * tiles_per_block;
+    const int n_vtiles = (a.V + 127) / 128;
+    const int n_my = min(tiles_per_block, n_vtiles - tile0);
     const int nap = a.vpos_terms ? a.vpos_terms : (*a.vpos_flag ? 3 : 1);
     const int nan_ = a.vneg_terms;
-
-    float4 wold[16], mold[16];
     const int colc = min(h0 + 4 * r, a.H - 4);
-    if constexpr (MODE == 0) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int64_t idx = (int64_t)min(vw + mfma_row(reg, l), a.V - 1) * a.ldw + colc;
-            wold[reg] = *reinterpret_cast<const float4*>(a.W + idx);
-            mold[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
-        }
-    }
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-    char* sHp = smem;                       // HT planes
-    char* sHn = smem + 3 * K3_PLANE;        // HT planes
-    char* sVa = smem + 6 * K3_PLANE;        // visible planes: pos then neg when both are single-term,
-    char* sVb = smem + 7 * K3_PLANE;        // otherwise the 2 planes + the free hidden slots are time-shared
-    const bool both = (nap == 1 && nan_ == 1);
-    for (int b0 = 0; b0 < a.Bp; b0 += 64) {
-        __syncthreads();
-        if (both) {
-            // everything of this chunk fits: one staging pass, one barrier, 8 MFMA k-blocks back to back
-            k3_stage<true>(sHp, a.hpos, a.hts, HT, h0, a.H, a.Bp, b0, false);
-            k3_stage<true>(sHn, a.hneg, a.hts, HT, h0, a.H, a.Bp, b0, false);
-            k3_stage<false>(sVa, a.vpos, a.vts, 1, v0, a.V, a.Bp, b0, false);
-            k3_stage<false>(sVb, a.vneg, a.vts, 1, v0, a.V, a.Bp, b0, true);
-            __syncthreads();
-            k3_mfma<HT, 1>(acc, sHp, sVa, w, r, kh);
-            k3_mfma<HT, 1>(acc, sHn, sVb, w, r, kh);
-        } else {
-            // real-valued visible activations (3 terms): positive and negative phase time-share the LDS
-            k3_stage<true>(sHp, a.hpos, a.hts, HT, h0, a.H, a.Bp, b0, false);
-            k3_stage<false>(sHn, a.vpos, a.vts, nap, v0, a.V, a.Bp, b0, false);
-            __syncthreads();
-            if (nap == 1) k3_mfma<HT, 1>(acc, sHp, sHn, w, r, kh); else k3_mfma<HT, 3>(acc, sHp, sHn, w, r, kh);
-            __syncthreads();
-            k3_stage<true>(sHp, a.hneg, a.hts, HT, h0, a.H, a.Bp, b0, false);
-            k3_stage<false>(sHn, a.vneg, a.vts, nan_, v0, a.V, a.Bp, b0, true);
-            __syncthreads();
-            if (nan_ == 1) k3_mfma<HT, 1>(acc, sHp, sHn, w, r, kh); else k3_mfma<HT, 3>(acc, sHp, sHn, w, r, kh);
-        }
-    }
-
     const bool cok = (h0 + 4 * r) < a.H;          // H % 4 == 0: a float4 is entirely inside or outside
+
+    char* sHp = smem;
+    char* sHn = smem + 3 * K3_PLANE;
+    char* sV0 = smem + 6 * K3_PLANE;            // two visible-plane buffers, alternating
+
+    auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0) {
+        if constexpr (MODE == 0) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = vw + mfma_row(reg, l);
-        if (row < a.V && cok) {
-            const float4 d = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);   // pos_assoc - neg_assoc
-            if constexpr (MODE == 0) {
-                const int64_t idx = (int64_t)row * a.ldw + h0 + 4 * r;
-                const float4 w0 = wold[reg];
-                float4 m = mold[reg];
-                m.x = m.x * a.mom; m.x = m.x + a.lr * (d.x / a.n - a.wd * w0.x);        // rbm.py:212
-                m.y = m.y * a.mom; m.y = m.y + a.lr * (d.y / a.n - a.wd * w0.y);
-                m.z = m.z * a.mom; m.z = m.z + a.lr * (d.z / a.n - a.wd * w0.z);
-                m.w = m.w * a.mom; m.w = m.w + a.lr * (d.w / a.n - a.wd * w0.w);
-                *reinterpret_cast<float4*>(a.Wm + idx) = m;
-                *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
-            } else {
-                *reinterpret_cast<float4*>(a.delta + (int64_t)row * a.H + h0 + 4 * r) = d;
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t idx = (int64_t)min(v0 + 32 * w + mfma_row(reg, l), a.V - 1) * a.ldw + colc;
+                wo[reg] = *reinterpret_cast<const float4*>(a.W + idx);
+                mo[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
             }
         }
+    };
+
+    float4 wA[16], mA[16], wB[16], mB[16];
+    load_tile(wA, mA, tile0 * 128);                                     // weight stream starts first
+    k3_stage<true, HT>(sHp, a.hpos, a.hts, h0, a.H, a.Bp, 0, false);    // hidden planes: once per block
+    k3_stage<true, HT>(sHn, a.hneg, a.hts, h0, a.H, a.Bp, 0, false);
+
+    int vbuf = 0;
+    auto tile = [&](int it, float4 (&wc)[16], float4 (&mc)[16], float4 (&wn)[16], float4 (&mn)[16]) {
+        const int v0 = (tile0 + it) * 128;
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        // positive then negative phase, one visible plane (term) at a time
+        for (int ph = 0; ph < 2; ++ph) {
+            const int nt_ = ph ? nan_ : nap;
+            for (int ta = 0; ta < nt_; ++ta) {
+                char* sVc = sV0 + vbuf * K3_PLANE;
+                k3_stage<false, 1>(sVc, (ph ? a.vneg : a.vpos) + ta * a.vts, 0, v0, a.V, a.Bp, 0, ph != 0);
+                __syncthreads();          // plane (and, first time, the hidden planes) visible to all waves
+                if (ph == 0 && ta == 0 && it + 1 < n_my) load_tile(wn, mn, v0 + 128);     // next tile's weights
+                k3_mfma<HT, 1>(acc, ph ? sHn : sHp, sVc, w, r, kh);
+                vbuf ^= 1;
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = v0 + 32 * w + mfma_row(reg, l);
+            if (row < a.V && cok) {
+                const float4 d = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);   // pos_assoc - neg_assoc
+                if constexpr (MODE == 0) {
+                    const int64_t idx = (int64_t)row * a.ldw + h0 + 4 * r;
+                    const float4 w0 = wc[reg];
+                    float4 m = mc[reg];
+                    m.x = m.x * a.mom; m.x = m.x + a.lr * (d.x / a.n - a.wd * w0.x);        // rbm.py:212
+                    m.y = m.y * a.mom; m.y = m.y + a.lr * (d.y / a.n - a.wd * w0.y);
+                    m.z = m.z * a.mom; m.z = m.z + a.lr * (d.z / a.n - a.wd * w0.z);
+                    m.w = m.w * a.mom; m.w = m.w + a.lr * (d.w / a.n - a.wd * w0.w);
+                    *reinterpret_cast<float4*>(a.Wm + idx) = m;
+                    *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
+                } else {
+                    *reinterpret_cast<float4*>(a.delta + (int64_t)row * a.H + h0 + 4 * r) = d;
+                }
+            }
+        }
+    };
+    for (int it = 0; it < n_my; it += 2) {
+        tile(it, wA, mA, wB, mB);
+        if (it + 1 < n_my) tile(it + 1, wB, mB, wA, mA);
     }
 }
 

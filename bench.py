@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--mode", default="parity", choices=["parity", "fast"])
     ap.add_argument("--ksplit-up", type=int, default=0)
     ap.add_argument("--ksplit-down", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     args = ap.parse_args()
 
     import torch
@@ -98,6 +99,9 @@ def main():
     eng.mode = native.FAST_BF16 if args.mode == "fast" else native.PARITY_F32
     if args.ksplit_up or args.ksplit_down:
         eng.set_tuning(args.ksplit_up, args.ksplit_down)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     if world > 1:
         E.dp.enable()
 

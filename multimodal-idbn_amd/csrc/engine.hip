@@ -22,7 +22,8 @@ namespace {
 
 thread_local char g_err[512] = "";
 int g_ks_up = 0, g_ks_down = 0;
-bool g_no_fast_k3 = false;    // tuning/testing: force the generic K3
+bool g_no_fast_k3 = false;
+int g_dbg = 0;    // tuning/testing: force the generic K3
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -111,7 +112,7 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.cs_hneg = (float*)take((size_t)L.P * H * 4);
     L.cs_vpos = (float*)take((size_t)L.P * V * 4);
     L.cs_vneg = (float*)take((size_t)L.P * V * 4);
-    L.n_loss_slots = cdiv(std::max(V, H), 64) * L.P + IMDBN_MAX_GROUPS;
+    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 32) * (L.Bp / 64)) + IMDBN_MAX_GROUPS;
     L.loss_part = (float*)take((size_t)L.n_loss_slots * 4);
     L.bytes = off;
     return L;
@@ -245,14 +246,25 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
         else
             hipLaunchKernelGGL(gemm_up_partial<1>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, L.partial, L.Bp, L.up.kchunk);
     } else {
-        dim3 grid(cdiv(L.V, 64), L.down.ks, mb);
+        // K2: fused GEMM + epilogue (no split-K slabs)
+        if (f.n_groups > 0 && !f.logits_only && !f.out_prob) f.out_prob = L.f_vp, f.ld_prob = L.V;
+        if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
+        dim3 grid(cdiv(L.V, 32), 1, mb);
+        f.dbg = g_dbg;
         const int64_t ats = (int64_t)L.Bp * L.Hpad;
-        const bool vec4 = (d->ldw % 4 == 0) && (((uintptr_t)d->W & 15) == 0);
+        const bool vec4 = (d->ldw % 4 == 0) && (((uintptr_t)d->W & 15) == 0) && (L.H % 4 == 0) && L.H >= 4;
+        if ((int)(grid.x * grid.z) + IMDBN_MAX_GROUPS > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
 #define LAUNCH_DOWN(NW, V4) \
-    hipLaunchKernelGGL((gemm_down_partial<NW, V4>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, L.partial, L.Bp, L.down.kchunk)
+    hipLaunchKernelGGL((gemm_down_fused<NW, V4>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f)
         if (c.nw == 3) { if (vec4) LAUNCH_DOWN(3, true); else LAUNCH_DOWN(3, false); }
         else           { if (vec4) LAUNCH_DOWN(1, true); else LAUNCH_DOWN(1, false); }
 #undef LAUNCH_DOWN
+        HIPCHK(hipGetLastError());
+        if (f.n_groups > 0 && !f.logits_only) {
+            hipLaunchKernelGGL(finish_groups, dim3(f.n_groups), dim3(64), 0, c.s, f, (int)(grid.x * grid.z));
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
     }
     HIPCHK(hipGetLastError());
     if (f.n_groups > 0 && !f.logits_only && !f.out_prob) f.out_prob = L.f_vp, f.ld_prob = L.V;
@@ -268,8 +280,8 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     return 0;
 }
 int n_loss_used(const Ctx& c, bool up) {
-    const int N = up ? c.L.H : c.L.V;
-    return cdiv(N, 64) * c.L.P + (up ? 0 : c.d->n_groups);
+    if (up) return cdiv(c.L.H, 64) * c.L.P;
+    return cdiv(c.L.V, 32) * (c.L.Bp / 64) + c.d->n_groups;      // fused K2: one partial per block
 }
 
 // caller fp32 tensor -> operand forms in the workspace
@@ -489,6 +501,7 @@ int imdbn_set_option(const char* name, int value) {
     if (!strcmp(name, "ksplit_up")) g_ks_up = std::max(0, value);
     else if (!strcmp(name, "ksplit_down")) g_ks_down = std::max(0, value);
     else if (!strcmp(name, "generic_k3")) g_no_fast_k3 = value != 0;
+    else if (!strcmp(name, "dbg")) g_dbg = value;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);
     return 0;
 }

@@ -66,6 +66,7 @@ struct FinishArgs {
     OperandOut op; int rm_src, tr_src;             // 0 none, 1 prob, 2 final
     float* colsum_part; int colsum_src;            // [Bp/32][N]
     const float* loss_ref; int64_t ld_ref; int loss_src; float* loss_part;   // one per block (+ one per group)
+    int dbg;                                       // timing experiments only: 1 = skip epilogue, 2 = skip GEMM loop
 };
 
 __device__ __forceinline__ bool in_group(const FinishArgs& a, int col) {
@@ -81,17 +82,81 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Epilogue of one column x 8 consecutive batch rows, given the pre-bias sums xs[8].
+// part_row = index of this 8-row group in the column-sum partials.  Returns the squared-error partial.
+__device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int b0, const float (&xs)[8], int part_row) {
+    const bool cok = col < a.N;
+    const bool grp = cok && in_group(a, col);
+    const int cc = min(col, a.N - 1);
+    const float bias = a.bias[cc];
+    // All side inputs are loaded up front, UNCONDITIONALLY, from clamped addresses (rows >= B and
+    // columns >= N are discarded below): a load inside the per-row branches would cost one dependent
+    // memory round trip per row.
+    float ref[8], mk[8], kn[8], mu[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int bc = min(b0 + i, a.B - 1);
+        ref[i] = a.loss_ref ? a.loss_ref[(int64_t)bc * a.ld_ref + cc] : 0.f;
+        mk[i] = a.clamp ? a.mask[(int64_t)bc * a.ldk + cc] : 0.f;
+        kn[i] = a.clamp ? a.vk[(int64_t)bc * a.ldk + cc] : 0.f;
+        mu[i] = (a.mu && cc < a.Dz) ? a.mu[(int64_t)bc * a.ldmu + cc] : 0.f;
+    }
+    const bool pull = a.mu && col < a.Dz;
+    float xp[8], xf[8];
+    float csum = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int b = b0 + i;
+        const bool live = cok && b < a.B;
+        const int bd = min(b, a.B - 1);             // draws for padded rows / columns: clamped, result discarded
+        float x = xs[i] + bias;
+        if (a.T != 1.0f) x = x / a.T;
+        if (a.sigma > 0.f) x = x + draw_normal(a.noise, bd, cc) * a.sigma;
+        float p = sigmoidf_ref(x);
+        if (pull) p = (1.0f - a.eta) * p + a.eta * mu[i];
+        const float mixed = a.clamp ? (p * (1.0f - mk[i]) + kn[i] * mk[i]) : p;
+        float v;
+        if (a.vmode == 0) {
+            v = mixed;
+        } else {
+            const float u = draw_uniform(a.uni, bd, cc);
+            if (a.vmode == 1) {
+                const float smp = (p > u) ? 1.f : 0.f;
+                v = a.clamp ? (smp * (1.0f - mk[i]) + kn[i] * mk[i]) : smp;
+            } else {
+                v = (mixed > u) ? 1.f : 0.f;
+            }
+        }
+        const bool raw = a.logits_only || grp;      // group columns: logits now, softmax etc. in finish_groups
+        if (live) {
+            if (a.out_prob) a.out_prob[(int64_t)b * a.ld_prob + col] = raw ? x : p;
+            if (a.out_final && !raw) a.out_final[(int64_t)b * a.ld_final + col] = v;
+        }
+        const bool use = live && !raw;
+        xp[i] = use ? p : 0.f;
+        xf[i] = use ? v : 0.f;
+        if (use) {
+            csum += (a.colsum_src == 2 ? v : p);
+            const float dlt = ref[i] - (a.loss_src == 2 ? v : p);
+            lsum += a.loss_ref ? dlt * dlt : 0.f;
+        }
+    }
+    if (!a.logits_only && !grp) {   // group columns get their operand forms from finish_groups
+        if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
+        if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
+    }
+    if (a.colsum_part && cok) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
+    return lsum;
+}
+
 __global__ __launch_bounds__(64) void finish(const FinishArgs a) {
     const int c = threadIdx.x;
     const int col = blockIdx.x * 64 + c;
     const int b0 = blockIdx.y * 8;
-    const bool cok = col < a.N;
-    const bool grp = cok && in_group(a, col);
-    const float bias = cok ? a.bias[col] : 0.f;
     float xs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) xs[i] = 0.f;
-    if (cok) {
+    if (col < a.N) {
         // split-K slab sum, k-sequential per element (deterministic); 8 rows x 4 slabs of loads in flight
         const float* pp = a.partial + (int64_t)b0 * a.N + col;
         int k = 0;
@@ -110,48 +175,7 @@ __global__ __launch_bounds__(64) void finish(const FinishArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) xs[i] += pp[(int64_t)k * a.slab + (int64_t)i * a.N];
     }
-    float xp[8], xf[8];
-    float csum = 0.f, lsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int b = b0 + i;
-        xp[i] = 0.f; xf[i] = 0.f;
-        if (!cok || b >= a.B) continue;
-        float x = xs[i] + bias;
-        if (a.T != 1.0f) x = x / a.T;
-        if (a.sigma > 0.f) x = x + draw_normal(a.noise, b, col) * a.sigma;
-        if (a.logits_only || grp) {                 // group columns: softmax etc. in finish_groups
-            if (a.out_prob) a.out_prob[(int64_t)b * a.ld_prob + col] = x;
-            continue;
-        }
-        float p = sigmoidf_ref(x);
-        if (a.mu && col < a.Dz) p = (1.0f - a.eta) * p + a.eta * a.mu[(int64_t)b * a.ldmu + col];
-        float v;
-        const float m = a.clamp ? a.mask[(int64_t)b * a.ldk + col] : 0.f;
-        const float kn = a.clamp ? a.vk[(int64_t)b * a.ldk + col] : 0.f;
-        if (a.vmode == 0) {
-            v = a.clamp ? (p * (1.0f - m) + kn * m) : p;
-        } else if (a.vmode == 1) {
-            const float s = (p > draw_uniform(a.uni, b, col)) ? 1.f : 0.f;
-            v = a.clamp ? (s * (1.0f - m) + kn * m) : s;
-        } else {
-            const float t = a.clamp ? (p * (1.0f - m) + kn * m) : p;
-            v = (t > draw_uniform(a.uni, b, col)) ? 1.f : 0.f;
-        }
-        if (a.out_prob) a.out_prob[(int64_t)b * a.ld_prob + col] = p;
-        if (a.out_final) a.out_final[(int64_t)b * a.ld_final + col] = v;
-        xp[i] = p; xf[i] = v;
-        csum += (a.colsum_src == 2 ? v : p);
-        if (a.loss_ref) {
-            const float d = a.loss_ref[(int64_t)b * a.ld_ref + col] - (a.loss_src == 2 ? v : p);
-            lsum += d * d;
-        }
-    }
-    if (!a.logits_only && !grp) {   // group columns get their operand forms from finish_groups
-        if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
-        if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
-    }
-    if (a.colsum_part && cok) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = csum;
+    const float lsum = finish_rows8(a, col, b0, xs, blockIdx.y);
     if (a.loss_part) {
         const float t = wave_sum(lsum);
         if (c == 0) a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
@@ -316,7 +340,15 @@ struct BiasArgs {
 
 __device__ __forceinline__ float sum_parts(const float* p, int P, int len, int i) {
     float s = 0.f;
-    for (int k = 0; k < P; ++k) s += p[(int64_t)k * len + i];
+    int k = 0;
+    for (; k + 8 <= P; k += 8) {          // 8 independent loads in flight, fixed summation order
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = p[(int64_t)(k + j) * len + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += t[j];
+    }
+    for (; k < P; ++k) s += p[(int64_t)k * len + i];
     return s;
 }
 

@@ -17,6 +17,7 @@
 //     128-B row segment per half-wave (W) or a 16-B piece of an L2-resident activation.
 #pragma once
 #include "common.hpp"
+#include "kernels_ew.hpp"
 
 namespace imdbn {
 
@@ -180,6 +181,122 @@ __global__ __launch_bounds__(256) void gemm_down_partial(
     const int na = a_terms ? a_terms : (*a_flag ? 3 : 1);
     if (na == 1) gemm_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
     else         gemm_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 fused with its epilogue (the hidden dimension K = H is short enough that no split-K is needed):
+// block = 4 waves on a 32(v) x 64(batch) tile, two blocks per CU so that all ceil(V/32) tiles of the
+// headline shape are resident in ONE round and two waves share each SIMD's VALU / matrix pipes; the waves
+// interleave 16-wide K blocks, each behind a 4-deep REGISTER RING of operand blocks (all loads of a block are
+// issued 4 blocks ahead, pinned with sched_barrier so the in-order vmcnt waits stay counted), reduce
+// through LDS, and the SAME per-element epilogue as `finish` (bias, /T, noise, sigmoid, mu-pull, clamp-mix,
+// Bernoulli sampling, operand forms, column sums, squared error) runs in-kernel: no slab round trip,
+// one launch less.  Softmax-group columns still leave logits for finish_groups.
+// grid = (ceil(V/32), 1, Bp/64), block = 256.
+// ------------------------------------------------------------------------------------------
+template <int NA>
+struct DownOperands {
+    float wv[8];
+    uint4 av[NA][2];
+};
+
+template <int NW, bool VEC4, int NA>
+__device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int64_t ldw, int K, int N,
+                                                const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
+                                                const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33]) {
+    constexpr int D = 4;                     // operand ring depth: D x (2 KB weights + activations) in flight per wave
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int n0 = blockIdx.x * 32, mb = blockIdx.z * 64;
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    const float* wrow = W + (int64_t)min(n0 + r, N - 1) * ldw;
+    const int64_t arow0 = (int64_t)(mb + r) * lda, arow1 = (int64_t)(mb + 32 + r) * lda;
+    auto load = [&](DownOperands<NA>& o, int kb) {
+        const int k0 = min(kb, lda - 16) + 8 * hh;      // clamped: blocks past the end are loaded but never used
+        if constexpr (VEC4) {
+            const float4 x0 = *reinterpret_cast<const float4*>(wrow + min(k0, K - 4));
+            const float4 x1 = *reinterpret_cast<const float4*>(wrow + min(k0 + 4, K - 4));
+            o.wv[0] = x0.x; o.wv[1] = x0.y; o.wv[2] = x0.z; o.wv[3] = x0.w;
+            o.wv[4] = x1.x; o.wv[5] = x1.y; o.wv[6] = x1.z; o.wv[7] = x1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.wv[j] = wrow[min(k0 + j, K - 1)];
+        }
+#pragma unroll
+        for (int ta = 0; ta < NA; ++ta) {
+            o.av[ta][0] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + arow0 + k0);
+            o.av[ta][1] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + arow1 + k0);
+        }
+    };
+    auto compute = [&](const DownOperands<NA>& o) {
+        uint4 bf[NW];
+        make_w_frags<NW>(o.wv, bf);
+#pragma unroll
+        for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int tw = 0; tw < NW; ++tw)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(o.av[ta][mt]), as_frag(bf[tw]), acc[mt], 0, 0, 0);
+    };
+    // wave w owns K blocks kb = 16*(w + 4*i); register ring of D blocks (statically indexed slots)
+    DownOperands<NA> ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(ring[d], 16 * (w + 4 * d));
+    for (int i0 = 0; 16 * (w + 4 * i0) < ((fa.dbg & 2) ? 0 : lda); i0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (16 * (w + 4 * (i0 + d)) < lda) compute(ring[d]);          // wave-uniform
+            __builtin_amdgcn_sched_barrier(0);
+            load(ring[d], 16 * (w + 4 * (i0 + d + D)));                   // refill the slot D blocks ahead
+        }
+    }
+    // cross-wave reduction (fixed order) into tile[batch row][column]
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) red[((w * 2 + mt) * 16 + reg) * 64 + l] = acc[mt][reg];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = w * 8 + i, mt = c >> 4, reg = c & 15;
+        const float s = ((red[((0 * 2 + mt) * 16 + reg) * 64 + l] + red[((1 * 2 + mt) * 16 + reg) * 64 + l]) +
+                         red[((2 * 2 + mt) * 16 + reg) * 64 + l]) + red[((3 * 2 + mt) * 16 + reg) * 64 + l];
+        tile[mt * 32 + mfma_row(reg, l)][r] = s;
+    }
+    __syncthreads();
+    // epilogue: 256 threads = 32 columns x 8 row-octets
+    const int c = tid & 31, oct = tid >> 5;
+    float xs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xs[i] = tile[oct * 8 + i][c];
+    float lsum = 0.f;
+    if (!(fa.dbg & 1)) lsum = finish_rows8(fa, n0 + c, mb + oct * 8, xs, (mb >> 3) + oct);
+    else if (xs[0] == 123.456f) fa.out_prob[0] = xs[1];
+    if (fa.loss_part) {
+        __syncthreads();
+        const float t = wave_sum(lsum);
+        if (l == 0) red[w] = t;
+        __syncthreads();
+        if (tid == 0) fa.loss_part[blockIdx.z * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+template <int NW, bool VEC4>
+__global__ __launch_bounds__(256, 2) void gemm_down_fused(
+    const float* __restrict__ W, int64_t ldw, int K, int N,
+    const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
+    const FinishArgs fa) {
+    __shared__ float red[4 * 32 * 64];
+    __shared__ float tile[64][33];
+    const int na = a_terms ? a_terms : (*a_flag ? 3 : 1);
+    if (na == 1) down_fused_body<NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
+    else         down_fused_body<NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -130,6 +130,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+    t_enq = time.perf_counter() - t0          # host time to enqueue all steps (== dt when host-bound)
     sync()
     dt = time.perf_counter() - t0
     k3_ms, k3_n = (eng.profile_read() if world == 1 else (0.0, 0))
@@ -154,6 +155,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
                        "final_loss": float(loss)},
+            "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
             "frac_hbm_roofline_whole_step": ups * 16.0 * V * H / (HBM_PEAK_GBS * 1e9),
             "frac_bf16_mfma_roofline_whole_step": ups * 10.0 * B * V * H / (BF16_PEAK_TFLOPS * 1e12),
         }

@@ -80,6 +80,18 @@ __device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(b
 // C/D layout of v_mfma_f32_32x32x16_bf16: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Term count of a caller-supplied activation operand from prep's exactness map [P][ncb] (one entry per
+// 8 batch rows x 64 features): OR of the entries of feature blocks [cb0, cb1) over all P row groups.
+// Wave-uniform result; map == nullptr means the count is static.
+__device__ __forceinline__ int operand_terms(const int* map, int ncb, int P, int cb0, int cb1, int static_terms) {
+    if (static_terms) return static_terms;
+    cb1 = min(cb1, ncb);
+    const int w = cb1 - cb0, n = w * P;
+    int any = 0;
+    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) any |= map[(i / w) * ncb + cb0 + (i % w)];
+    return __any(any) ? 3 : 1;
+}
+
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace imdbn

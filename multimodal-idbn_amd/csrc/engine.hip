@@ -23,6 +23,7 @@ namespace {
 thread_local char g_err[512] = "";
 int g_ks_up = 0, g_ks_down = 0;
 bool g_no_fast_k3 = false;
+bool g_no_fast_k1 = false;
 int g_dbg = 0;    // tuning/testing: force the generic K3
 
 int fail(int code, const char* fmt, ...) {
@@ -73,7 +74,8 @@ Split plan_split(int Kpad, int n_tiles, int m_blocks, int forced, int cap) {
 struct Layout {
     int V, H, B, Bp, Vpad, Hpad, P;
     Split up, down;
-    int* flags;
+    bool up4;
+    int* flags; int* flags_h;
     bf16_t* vis_rm[2];
     bf16_t* vis_tr[2];
     bf16_t* hid_rm;
@@ -94,11 +96,20 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.Vpad = rup(V, 16); L.Hpad = rup(H, 16);
     L.P = L.Bp / 8;
     const int mb = L.Bp / 64;
-    L.up = plan_split(L.Vpad, cdiv(H, 64), mb, g_ks_up, 64);
+    L.up4 = (H % 4 == 0) && H >= 4 && !g_no_fast_k1;      // float4 K1 (also needs 16-B aligned W: checked at launch)
+    if (L.up4) {
+        const int tiles = cdiv(H, 128) * mb;
+        const int want = g_ks_up > 0 ? g_ks_up : std::max(1, 252 / std::max(1, tiles));
+        L.up = plan_split(L.Vpad, cdiv(H, 128), mb, want, 64);
+    } else {
+        L.up = plan_split(L.Vpad, cdiv(H, 64), mb, g_ks_up, 64);
+    }
     L.down = plan_split(L.Hpad, cdiv(V, 64), mb, g_ks_down, 16);
     size_t off = 0;
     auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return p; };
-    L.flags = (int*)take(256);
+    // exactness maps of caller-supplied operands (prep rewrites them every call): visible side, hidden side
+    L.flags = (int*)take((size_t)L.P * cdiv(L.Vpad, 64) * 4);
+    L.flags_h = (int*)take((size_t)L.P * cdiv(L.Hpad, 64) * 4);
     for (int i = 0; i < 2; ++i) L.vis_rm[i] = (bf16_t*)take((size_t)3 * L.Bp * L.Vpad * 2);
     for (int i = 0; i < 2; ++i) L.vis_tr[i] = (bf16_t*)take((size_t)3 * V * L.Bp * 2);
     L.hid_rm = (bf16_t*)take((size_t)3 * L.Bp * L.Hpad * 2);
@@ -202,7 +213,6 @@ int setup(Ctx& c, int B, void* ws, size_t ws_bytes) {
     c.L = make_layout(c.d->V, c.d->H, B, (char*)ws);
     if (c.L.bytes > ws_bytes)
         return fail(IMDBN_E_WORKSPACE, "workspace %zu < %zu bytes needed for V=%d H=%d B=%d", ws_bytes, c.L.bytes, c.d->V, c.d->H, B);
-    HIPCHK(hipMemsetAsync(c.L.flags, 0, 256, c.s));
     return 0;
 }
 
@@ -221,6 +231,7 @@ void base_finish_args(Ctx& c, bool up, FinishArgs& f) {
     for (int g = 0; g < IMDBN_MAX_GROUPS; ++g) { f.gs[g] = up ? 0 : c.d->group_start[g]; f.ge[g] = up ? 0 : c.d->group_end[g]; }
     f.op.ldrm = up ? L.Hpad : L.Vpad;
     f.op.rm_ts = (int64_t)L.Bp * f.op.ldrm;
+    f.op.Bp = L.Bp;
     f.op.tr_ts = (int64_t)f.N * L.Bp;
 }
 
@@ -239,12 +250,21 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     if (f.T < 1e-6f) f.T = 1e-6f;                           // max(1e-6, T)  rbm.py:92,96
     const int mb = L.Bp / 64;
     if (up) {
-        dim3 grid(cdiv(L.H, 64), L.up.ks, mb);
         const int64_t ats = (int64_t)L.Bp * L.Vpad;
-        if (c.nw == 3)
-            hipLaunchKernelGGL(gemm_up_partial<3>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, L.partial, L.Bp, L.up.kchunk);
-        else
-            hipLaunchKernelGGL(gemm_up_partial<1>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, L.partial, L.Bp, L.up.kchunk);
+        const bool fast = L.up4 && d->ldw % 4 == 0 && (((uintptr_t)d->W) & 15) == 0;
+        if (fast) {
+            dim3 grid(cdiv(L.H, 128), L.up.ks, mb);
+            if (c.nw == 3)
+                hipLaunchKernelGGL(gemm_up4_partial<3>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, L.partial, L.Bp, L.up.kchunk, g_dbg >> 4);
+            else
+                hipLaunchKernelGGL(gemm_up4_partial<1>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, L.partial, L.Bp, L.up.kchunk, g_dbg >> 4);
+        } else {
+            dim3 grid(cdiv(L.H, 64), L.up.ks, mb);
+            if (c.nw == 3)
+                hipLaunchKernelGGL(gemm_up_partial<3>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, L.partial, L.Bp, L.up.kchunk);
+            else
+                hipLaunchKernelGGL(gemm_up_partial<1>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, L.partial, L.Bp, L.up.kchunk);
+        }
     } else {
         // K2: fused GEMM + epilogue (no split-K slabs)
         if (f.n_groups > 0 && !f.logits_only && !f.out_prob) f.out_prob = L.f_vp, f.ld_prob = L.V;
@@ -271,7 +291,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
     dim3 fgrid(cdiv(f.N, 64), L.P);
     if ((int)(fgrid.x * fgrid.y) + IMDBN_MAX_GROUPS > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
-    hipLaunchKernelGGL(finish, fgrid, dim3(64), 0, c.s, f);
+    hipLaunchKernelGGL(finish, fgrid, dim3(256), 0, c.s, f);
     HIPCHK(hipGetLastError());
     if (f.n_groups > 0 && !f.logits_only) {
         hipLaunchKernelGGL(finish_groups, dim3(f.n_groups), dim3(64), 0, c.s, f, (int)(fgrid.x * fgrid.y));
@@ -290,7 +310,7 @@ int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_
     PrepArgs p;
     memset(&p, 0, sizeof(p));
     p.in = in; p.ld = ld; p.B = c.L.B; p.Bp = c.L.Bp; p.N = N;
-    p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = 3;
+    p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = 3; p.op.Bp = c.L.Bp;
     p.op.tr = tr; p.op.tr_ts = (int64_t)N * c.L.Bp; p.op.tr_terms = 3;
     p.flag = flag;
     p.colsum_part = colsum;
@@ -419,7 +439,7 @@ int run_chain(Ctx& c, const float* vk, const float* mask, int64_t ldk, int init_
         p.in = vk; p.ld = ldk; p.B = B; p.Bp = L.Bp; p.N = L.V;
         if (init_uniform) { p.mix = 1; p.mask = mask; p.ldm = ldk; p.uni = c.rng.floats(B, L.V); }
         p.out_f32 = out; p.ldo = ldo;
-        p.op.rm = L.vis_rm[0]; p.op.ldrm = L.Vpad; p.op.rm_ts = (int64_t)L.Bp * L.Vpad; p.op.rm_terms = c.rt;
+        p.op.rm = L.vis_rm[0]; p.op.ldrm = L.Vpad; p.op.rm_ts = (int64_t)L.Bp * L.Vpad; p.op.rm_terms = c.rt; p.op.Bp = L.Bp;
         if (want_stats && n_steps == 0) {
             p.op.tr = L.vis_tr[0]; p.op.tr_ts = (int64_t)L.V * L.Bp; p.op.tr_terms = c.rt;
             p.colsum_part = L.cs_vpos;
@@ -502,6 +522,7 @@ int imdbn_set_option(const char* name, int value) {
     else if (!strcmp(name, "ksplit_down")) g_ks_down = std::max(0, value);
     else if (!strcmp(name, "generic_k3")) g_no_fast_k3 = value != 0;
     else if (!strcmp(name, "dbg")) g_dbg = value;
+    else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);
     return 0;
 }
@@ -555,11 +576,11 @@ int imdbn_rbm_prop_down(const imdbn_rbm_desc* d, const float* h, int64_t ldh, in
     if (!h || !out_prob || ldh < d->H || ldo < d->V) return fail(IMDBN_E_INVALID, "prop_down: bad tensor argument");
     Ctx c(d, nullptr, S(stream));
     CHK(setup(c, B, ws, ws_bytes));
-    CHK(prep(c, h, ldh, d->H, c.L.hid_rm, c.L.Hpad, nullptr, c.L.flags + 1));
+    CHK(prep(c, h, ldh, d->H, c.L.hid_rm, c.L.Hpad, nullptr, c.L.flags_h));
     FinishArgs f = new_finish();
     f.T = T; f.logits_only = logits_only;
     f.out_prob = out_prob; f.ld_prob = ldo;
-    CHK(prop(c, false, OpIn{c.L.hid_rm, c.nw == 1 ? 1 : 0, c.L.flags + 1}, f));
+    CHK(prop(c, false, OpIn{c.L.hid_rm, c.nw == 1 ? 1 : 0, c.L.flags_h}, f));
     return 0;
 }
 

@@ -18,7 +18,10 @@
 namespace imdbn {
 
 struct OperandOut {
-    bf16_t* rm; int64_t rm_ts; int ldrm; int rm_terms;   // row-major   [t][Bp][ldrm]
+    // "row-major" operand (A of K1/K2), stored K16-BLOCKED: element (b, k) of term t at
+    //   rm[t*rm_ts + ((k>>4)*Bp + b)*16 + (k&15)],   k < ldrm (= feature count padded to 16)
+    // so the MFMA A-fragment load of a wave (32 rows x 2 halves x 16 B) is ONE contiguous KB.
+    bf16_t* rm; int64_t rm_ts; int ldrm; int rm_terms; int Bp;
     bf16_t* tr; int64_t tr_ts; int tr_terms;             // transposed  [t][N][Bp]
 };
 
@@ -35,7 +38,7 @@ __device__ __forceinline__ void store_rm(const OperandOut& o, const float (&x)[8
         for (int t = 0; t < o.rm_terms; ++t)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                o.rm[t * o.rm_ts + (int64_t)(b0 + i) * o.ldrm + col] = (bf16_t)piece(x[i], t, o.rm_terms);
+                o.rm[t * o.rm_ts + ((int64_t)(col >> 4) * o.Bp + (b0 + i)) * 16 + (col & 15)] = (bf16_t)piece(x[i], t, o.rm_terms);
     }
 }
 __device__ __forceinline__ void store_tr(const OperandOut& o, const float (&x)[8], int b0, int col, int N, int Bp) {
@@ -149,36 +152,50 @@ __device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int 
     return lsum;
 }
 
-__global__ __launch_bounds__(64) void finish(const FinishArgs a) {
-    const int c = threadIdx.x;
+// block = 256 threads = 64 columns x 4 slab-quarters: thread (c, kq) sums slabs k = kq, kq+4, ... of its
+// column for 8 rows (all loads of a quarter in flight together), the quarters are combined through LDS in
+// a fixed order, and wave 0 runs the per-element epilogue.  grid = (ceil(N/64), Bp/8).
+__global__ __launch_bounds__(256) void finish(const FinishArgs a) {
+    __shared__ float part[3][8][64];
+    const int c = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
     const int b0 = blockIdx.y * 8;
     float xs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) xs[i] = 0.f;
     if (col < a.N) {
-        // split-K slab sum, k-sequential per element (deterministic); 8 rows x 4 slabs of loads in flight
-        const float* pp = a.partial + (int64_t)b0 * a.N + col;
-        int k = 0;
-        for (; k + 4 <= a.ks; k += 4) {
-            float t[4][8];
+        const float* pp = a.partial + (int64_t)b0 * a.N + col;      // rows < Bp always exist
+        // the slabs were written by other XCDs: every dependent batch of loads costs a full fabric round
+        // trip, so a thread issues ALL its loads (up to 8 slabs x 8 rows) before the first add
+        for (int k = kq; k < a.ks; k += 32) {
+            float t[8][8];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 8; ++kk) {
+                const int ks_ = min(k + 4 * kk, a.ks - 1);          // clamped, masked below
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t[kk][i] = pp[(int64_t)(k + kk) * a.slab + (int64_t)i * a.N];   // rows < Bp always exist
+                for (int i = 0; i < 8; ++i) t[kk][i] = pp[(int64_t)ks_ * a.slab + (int64_t)i * a.N];
+            }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 8; ++kk) {
+                const float live = (k + 4 * kk < a.ks) ? 1.0f : 0.0f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xs[i] += t[kk][i];
+                for (int i = 0; i < 8; ++i) xs[i] += live * t[kk][i];
+            }
         }
-        for (; k < a.ks; ++k)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xs[i] += pp[(int64_t)k * a.slab + (int64_t)i * a.N];
     }
-    const float lsum = finish_rows8(a, col, b0, xs, blockIdx.y);
-    if (a.loss_part) {
-        const float t = wave_sum(lsum);
-        if (c == 0) a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    if (kq > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[kq - 1][i][c] = xs[i];
+    }
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xs[i] = ((xs[i] + part[0][i][c]) + part[1][i][c]) + part[2][i][c];
+        const float lsum = finish_rows8(a, col, b0, xs, blockIdx.y);
+        if (a.loss_part) {
+            const float t = wave_sum(lsum);
+            if (c == 0) a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+        }
     }
 }
 
@@ -297,7 +314,7 @@ struct PrepArgs {
     const float* in; int64_t ld; int B, Bp, N;
     int mix; const float* mask; int64_t ldm; DrawSrc uni;
     float* out_f32; int64_t ldo;
-    OperandOut op; int* flag;      // flag |= 1 if any element is not exactly one bf16 term
+    OperandOut op; int* flag;      // exactness map [Bp/8][ceil(N/64)]: 1 = some element of the tile needs 3 bf16 terms
     float* colsum_part;            // [Bp/8][N] column sums over each 8-row group (sum data, rbm.py:223)
 };
 
@@ -324,7 +341,8 @@ __global__ __launch_bounds__(64) void prep_operand(const PrepArgs a) {
             inexact |= (__float_as_uint(v) & 0xFFFFu) != 0u;
         }
     }
-    if (a.flag && inexact) atomicOr(a.flag, 1);
+    // plain store, rewritten by every call: no zeroing / atomics; consumers OR the entries they cover
+    if (a.flag) { const bool any = __any(inexact ? 1 : 0) != 0; if (c == 0) a.flag[blockIdx.y * gridDim.x + blockIdx.x] = any ? 1 : 0; }
     if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = csum;
     store_rm(a.op, x, b0, col);
     store_tr(a.op, x, b0, col, a.N, a.Bp);

@@ -9,7 +9,8 @@
 //     into registers in the MFMA B-fragment shape, and split in registers into NW bf16 terms
 //     (NW=3: hi+mid+lo == w exactly -> fp32-exact products; NW=1: round-to-nearest bf16).
 //   * Activations arrive pre-split in bf16 "operand form" written by the finish/prep kernels:
-//       row-major   rm[t][Bp][Kpad]   (A operand of K1/K2: 8 consecutive k per lane = one 16-B load)
+//       "row-major" rm[t][Kpad/16][Bp][16], K16-blocked (A operand of K1/K2: 8 consecutive k per lane =
+//                   one 16-B load, and a wave's 64 loads form one contiguous KB)
 //       transposed  tr[t][N][Bp]      (A/B operands of K3: 8 consecutive batch rows per lane)
 //     with t = 1 term for {0,1} samples and 3 terms for real-valued activations (a flag in device
 //     memory decides for caller-supplied data), Bp = batch padded to 64 with zero rows.
@@ -82,7 +83,7 @@ struct GemmOperands {
 template <bool UP, bool VEC4, int NA>
 __device__ __forceinline__ void gemm_load(GemmOperands<NA>& o, const float* const (&wbase)[2], int64_t ldw, int K,
                                           const bf16_t* Abase, int64_t a_term_stride, int64_t arow0, int64_t arow1,
-                                          int kb, int hh) {
+                                          int kb, int hh, int Bp_) {
     const int k0 = kb + 8 * hh;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -101,8 +102,9 @@ __device__ __forceinline__ void gemm_load(GemmOperands<NA>& o, const float* cons
     }
 #pragma unroll
     for (int ta = 0; ta < NA; ++ta) {
-        o.av[ta][0] = *reinterpret_cast<const uint4*>(Abase + ta * a_term_stride + arow0 + k0);
-        o.av[ta][1] = *reinterpret_cast<const uint4*>(Abase + ta * a_term_stride + arow1 + k0);
+        // K16-blocked operand: (row, kb) -> ((kb/16)*Bp + row)*16 ; arow0/arow1 carry Bp-relative row offsets
+        o.av[ta][0] = *reinterpret_cast<const uint4*>(Abase + ta * a_term_stride + ((int64_t)(kb >> 4) * Bp_ + arow0) * 16 + 8 * hh);
+        o.av[ta][1] = *reinterpret_cast<const uint4*>(Abase + ta * a_term_stride + ((int64_t)(kb >> 4) * Bp_ + arow1) * 16 + 8 * hh);
     }
 }
 
@@ -129,7 +131,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ W, int64_t l
         const int n = min(n0 + nt * 32 + r, N - 1);
         wbase[nt] = UP ? (W + n) : (W + (int64_t)n * ldw);
     }
-    const int64_t arow0 = (int64_t)(mb + r) * lda, arow1 = (int64_t)(mb + 32 + r) * lda;
+    const int64_t arow0 = mb + r, arow1 = mb + 32 + r;
 
     auto compute = [&](const GemmOperands<NA>& o) {
         uint4 bf[2][NW];
@@ -147,10 +149,10 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ W, int64_t l
     };
     const int kb0 = k_begin + 16 * w;
     GemmOperands<NA> cur, nxt;
-    if (kb0 < k_end) gemm_load<UP, VEC4, NA>(cur, wbase, ldw, K, A, a_term_stride, arow0, arow1, kb0, hh);
+    if (kb0 < k_end) gemm_load<UP, VEC4, NA>(cur, wbase, ldw, K, A, a_term_stride, arow0, arow1, kb0, hh, Bp);
     for (int kb = kb0; kb < k_end; kb += 64) {
         // next block's operands: one load group, pinned ahead of this block's math
-        gemm_load<UP, VEC4, NA>(nxt, wbase, ldw, K, A, a_term_stride, arow0, arow1, min(kb + 64, lda - 16), hh);
+        gemm_load<UP, VEC4, NA>(nxt, wbase, ldw, K, A, a_term_stride, arow0, arow1, min(kb + 64, lda - 16), hh, Bp);
         __builtin_amdgcn_sched_barrier(0);
         compute(cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_up_partial(
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
     float* __restrict__ partial, int Bp, int kchunk) {
     __shared__ float red[4][2][16][64];
-    const int na = a_terms ? a_terms : (*a_flag ? 3 : 1);
+    const int na = operand_terms(a_flag, (lda + 63) / 64, Bp / 8, (blockIdx.y * kchunk) / 64, (blockIdx.y * kchunk + kchunk + 63) / 64, a_terms);
     if (na == 1) gemm_body<true, NW, false, 1>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
     else         gemm_body<true, NW, false, 3>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
 }
@@ -178,9 +180,122 @@ __global__ __launch_bounds__(256) void gemm_down_partial(
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
     float* __restrict__ partial, int Bp, int kchunk) {
     __shared__ float red[4][2][16][64];
-    const int na = a_terms ? a_terms : (*a_flag ? 3 : 1);
+    const int na = operand_terms(a_flag, (lda + 63) / 64, Bp / 8, (blockIdx.y * kchunk) / 64, (blockIdx.y * kchunk + kchunk + 63) / 64, a_terms);
     if (na == 1) gemm_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
     else         gemm_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1, fast path (N % 4 == 0, 16-B aligned weight rows): float4 weight loads.
+// A wave owns 64(batch) x 128(columns) as 2 x 4 MFMA tiles whose columns are INTERLEAVED
+// (column of tile t, lane r = n0 + 4r + t): one float4 per lane per K row -> 512-B contiguous row
+// segments per half-wave (1.4x the bandwidth of the dword shape, tools/membench).  One wave per SIMD
+// with a 2-deep register ring of operand blocks (8 float4 weights + activation fragments per slot);
+// ~one block per CU (ksplit = CUs / column tiles), so the split-K slabs shrink to ~8 MB.
+// grid = (ceil(N/128), ksplit, Bp/64), block = 256 (the 4 waves interleave 16-row K blocks).
+// ------------------------------------------------------------------------------------------
+template <int NA>
+struct UpOperands {
+    float4 wv[8];
+    uint4 av[NA][2];
+};
+
+template <int NW, int NA>
+__device__ __forceinline__ void up4_body(const float* __restrict__ W, int64_t ldw, int K, int N,
+                                         const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
+                                         float* __restrict__ partial, int Bp, int kchunk, float* red /*[4][4][16][64]*/, int dbg) {
+    constexpr int D = 2;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+    const int n0 = blockIdx.x * 128, ks = blockIdx.y, mb = blockIdx.z * 64;
+    const int k_begin = ks * kchunk;
+    const int k_end = min(k_begin + kchunk, lda);
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.f;
+    const float* wcol = W + min(n0 + 4 * r, N - 4);
+    const int64_t arow0 = mb + r, arow1 = mb + 32 + r;
+    auto load = [&](UpOperands<NA>& o, int kb) {
+        const int kbc = min(kb, lda - 16);                  // clamped: blocks past the end are loaded but never used
+        const int k0 = kbc + 8 * hh;
+        const int64_t ablk = (int64_t)(kbc >> 4) * Bp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.wv[j] = *reinterpret_cast<const float4*>(wcol + (int64_t)min(k0 + j, K - 1) * ldw);
+#pragma unroll
+        for (int ta = 0; ta < NA; ++ta) {
+            o.av[ta][0] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow0) * 16 + 8 * hh);
+            o.av[ta][1] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow1) * 16 + 8 * hh);
+        }
+    };
+    auto compute = [&](const UpOperands<NA>& o) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = t == 0 ? o.wv[j].x : (t == 1 ? o.wv[j].y : (t == 2 ? o.wv[j].z : o.wv[j].w));
+            uint4 bf[NW];
+            make_w_frags<NW>(x, bf);
+#pragma unroll
+            for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int tw = 0; tw < NW; ++tw)
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(o.av[ta][mt]), as_frag(bf[tw]), acc[mt][t], 0, 0, 0);
+        }
+    };
+    UpOperands<NA> ring[D];
+    const int kb0 = k_begin + 16 * w;
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(ring[d], kb0 + 64 * d);
+    for (int kb = kb0; kb < k_end; kb += 64 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 64 * d < k_end && !(dbg & 1)) compute(ring[d]);      // wave-uniform
+            else if (dbg & 1) acc[0][0][0] += ring[d].wv[0].x + __uint_as_float(ring[d].av[0][0].x);
+            __builtin_amdgcn_sched_barrier(0);
+            load(ring[d], kb + 64 * (d + D));                             // refill D blocks ahead
+        }
+    }
+    // cross-wave reduction (fixed order) and float4 slab stores: thread -> 4 interleaved columns of one row
+    float* slab = partial + (int64_t)ks * Bp * N;
+    const bool cok = (n0 + 4 * r) < N;
+    if (dbg & 2) { if (acc[0][0][0] == 123.456f) slab[0] = 1.f; return; }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) red[((w * 4 + t) * 16 + reg) * 64 + l] = acc[mt][t][reg];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int reg = w * 4 + i;
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                v[t] = ((red[((0 * 4 + t) * 16 + reg) * 64 + l] + red[((1 * 4 + t) * 16 + reg) * 64 + l]) +
+                        red[((2 * 4 + t) * 16 + reg) * 64 + l]) + red[((3 * 4 + t) * 16 + reg) * 64 + l];
+            const int row = mb + mt * 32 + mfma_row(reg, l);
+            if (cok) *reinterpret_cast<float4*>(slab + (int64_t)row * N + n0 + 4 * r) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256, 1) void gemm_up4_partial(
+    const float* __restrict__ W, int64_t ldw, int K, int N,
+    const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
+    float* __restrict__ partial, int Bp, int kchunk, int dbg) {
+    __shared__ float red[4 * 4 * 16 * 64];      // 64 KB
+    const int na = operand_terms(a_flag, (lda + 63) / 64, Bp / 8, (blockIdx.y * kchunk) / 64, (blockIdx.y * kchunk + kchunk + 63) / 64, a_terms);
+    if (na == 1) up4_body<NW, 1>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red, dbg);
+    else         up4_body<NW, 3>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red, dbg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -213,9 +328,11 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
     const float* wrow = W + (int64_t)min(n0 + r, N - 1) * ldw;
-    const int64_t arow0 = (int64_t)(mb + r) * lda, arow1 = (int64_t)(mb + 32 + r) * lda;
+    const int64_t arow0 = mb + r, arow1 = mb + 32 + r;
     auto load = [&](DownOperands<NA>& o, int kb) {
-        const int k0 = min(kb, lda - 16) + 8 * hh;      // clamped: blocks past the end are loaded but never used
+        const int kbc = min(kb, lda - 16);              // clamped: blocks past the end are loaded but never used
+        const int k0 = kbc + 8 * hh;
+        const int64_t ablk = (int64_t)(kbc >> 4) * fa.Bp;
         if constexpr (VEC4) {
             const float4 x0 = *reinterpret_cast<const float4*>(wrow + min(k0, K - 4));
             const float4 x1 = *reinterpret_cast<const float4*>(wrow + min(k0 + 4, K - 4));
@@ -227,8 +344,8 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
         }
 #pragma unroll
         for (int ta = 0; ta < NA; ++ta) {
-            o.av[ta][0] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + arow0 + k0);
-            o.av[ta][1] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + arow1 + k0);
+            o.av[ta][0] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow0) * 16 + 8 * hh);
+            o.av[ta][1] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow1) * 16 + 8 * hh);
         }
     };
     auto compute = [&](const DownOperands<NA>& o) {
@@ -242,17 +359,20 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
                 for (int tw = 0; tw < NW; ++tw)
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(o.av[ta][mt]), as_frag(bf[tw]), acc[mt], 0, 0, 0);
     };
-    // wave w owns K blocks kb = 16*(w + 4*i); register ring of D blocks (statically indexed slots)
+    // K blocks are dealt to the waves in groups of D CONSECUTIVE blocks (group g of wave w = blocks
+    // (4g+w)*D .. +D-1), so one pass over the ring reads D*64 B = 256 contiguous bytes of every weight row
+    // (whole 128-B lines per wave instead of lines split between waves).  Register ring, static slots.
     DownOperands<NA> ring[D];
+    const int nblk = lda / 16;
 #pragma unroll
-    for (int d = 0; d < D; ++d) load(ring[d], 16 * (w + 4 * d));
-    for (int i0 = 0; 16 * (w + 4 * i0) < ((fa.dbg & 2) ? 0 : lda); i0 += D) {
+    for (int d = 0; d < D; ++d) load(ring[d], 16 * (w * D + d));
+    for (int g = 0; (4 * g + w) * D < ((fa.dbg & 2) ? 0 : nblk); ++g) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             __builtin_amdgcn_sched_barrier(0);
-            if (16 * (w + 4 * (i0 + d)) < lda) compute(ring[d]);          // wave-uniform
+            if ((4 * g + w) * D + d < nblk) compute(ring[d]);             // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
-            load(ring[d], 16 * (w + 4 * (i0 + d + D)));                   // refill the slot D blocks ahead
+            load(ring[d], 16 * ((4 * (g + 1) + w) * D + d));              // refill the slot for the next group
         }
     }
     // cross-wave reduction (fixed order) into tile[batch row][column]
@@ -294,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void gemm_down_fused(
     const FinishArgs fa) {
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
-    const int na = a_terms ? a_terms : (*a_flag ? 3 : 1);
+    const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
     if (na == 1) down_fused_body<NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
     else         down_fused_body<NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
 }
@@ -435,8 +555,10 @@ __device__ __forceinline__ void assoc_body(const AssocArgs& a) {
 // fully static body so every fragment load can be issued ahead of its MFMAs.
 template <int MODE, int HT>
 __global__ __launch_bounds__(256) void assoc_update(const AssocArgs a) {
-    const int nap = a.vpos_terms ? a.vpos_terms : (*a.vpos_flag ? 3 : 1);
-    const int nan_ = a.vneg_terms ? a.vneg_terms : (*a.vneg_flag ? 3 : 1);
+    const int ncb = (a.V + 15) / 16 * 16;      // prep's map covers ceil(Vpad/64) feature blocks
+    const int v0b = blockIdx.y * 64;
+    const int nap = operand_terms(a.vpos_flag, (ncb + 63) / 64, a.Bp / 8, v0b / 64, v0b / 64 + 1, a.vpos_terms);
+    const int nan_ = a.vneg_terms;
     if (nap == 1) {
         if (nan_ == 1) assoc_body<MODE, HT, 1, 1>(a);
         else           assoc_body<MODE, HT, 1, 3>(a);
@@ -544,7 +666,8 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
     const int tile0 = blockIdx.y * tiles_per_block;
     const int n_vtiles = (a.V + 127) / 128;
     const int n_my = min(tiles_per_block, n_vtiles - tile0);
-    const int nap = a.vpos_terms ? a.vpos_terms : (*a.vpos_flag ? 3 : 1);
+    const int ncbv = ((a.V + 15) / 16 * 16 + 63) / 64;
+    const int nap = operand_terms(a.vpos_flag, ncbv, a.Bp / 8, (tile0 * 128) / 64, (tile0 + tiles_per_block) * 2, a.vpos_terms);
     const int nan_ = a.vneg_terms;
     const int colc = min(h0 + 4 * r, a.H - 4);
     const bool cok = (h0 + 4 * r) < a.H;          // H % 4 == 0: a float4 is entirely inside or outside

@@ -1,0 +1,52 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/imdbn_engine.h declares
+(no compute calls -- there is no GPU here), and size helpers are consistent."""
+import os
+import re
+
+from imdbn.engine import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "imdbn_engine.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(imdbn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = native.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+        assert s in native.SIGNATURES, f"{s} has no ctypes signature in imdbn/engine/native.py"
+    assert sorted(native.SIGNATURES) == syms, "ctypes binding lists symbols the header does not declare"
+
+
+def test_version_and_sizes():
+    lib = native.lib()
+    assert lib.imdbn_version() == 1
+    assert lib.imdbn_ws_bytes(10000, 1500, 64) > 0
+    assert lib.imdbn_ws_bytes(10000, 1500, 64) <= 128 << 20        # scratch stays small next to 288 GB
+    assert lib.imdbn_ws_bytes(0, 10, 1) == 0
+    assert lib.imdbn_ws_bytes(784, 256, 32) == lib.imdbn_ws_bytes(784, 256, 64)   # batch is padded to 64
+
+
+def test_struct_sizes_match_header_layout():
+    import ctypes as C
+    assert C.sizeof(native.RbmDesc) == 8 * 7 + 4 * 4 + 4 * 8
+    assert C.sizeof(native.Rng) == 8 + 8 * 3 + 8 * 4 + 8 * 3
+    assert C.sizeof(native.ChainStep) == 24
+    assert C.sizeof(native.CdOpts) == 36
+
+
+def test_no_gpu_call_reports_nodevice_as_exception():
+    import torch
+    import pytest
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from imdbn.engine.hip_engine import HipEngine
+    eng = HipEngine()
+    with pytest.raises(native.EngineError):
+        eng.device_info()

@@ -162,8 +162,16 @@ def main():
         if world == 1 and k3_n > 0:
             avg_s = 1e-3 * k3_ms / k3_n
             ach = 16.0 * V * H / avg_s / 1e9
+            traffic, tsrc = None, None        # HBM bytes per launch from the committed PMC passes of this same command
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                for k, d in pm["kernels"].items():
+                    if "assoc_update" in k:
+                        traffic, tsrc = d["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)"
+            except Exception:
+                pass
             out["roofline"] = {"kernel": "assoc_update (K3)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                                "avg_launch_us": 1e6 * avg_s, "launches": k3_n,
                                "algorithmic_bytes_per_launch": 16 * V * H}
         else:

@@ -94,11 +94,16 @@ class HipEngine:
                 m = getattr(rbm, nm, None)
                 if m is None or m.shape != ref.shape:
                     m = torch.zeros_like(ref)
-                elif m.device != ref.device or m.dtype != torch.float32 or not m.is_contiguous():
-                    m = m.to(device=ref.device, dtype=torch.float32).contiguous()
+                elif m.device != ref.device or m.dtype != torch.float32:
+                    m = m.to(device=ref.device, dtype=torch.float32)
+                if nm != "W_m" and not m.is_contiguous():
+                    m = m.contiguous()
                 setattr(rbm, nm, m)
-            if rbm.W_m.stride(0) != W.stride(0):
-                raise N.EngineError("W_m must share W's row stride")
+            if rbm.W_m.stride(0) != W.stride(0) or rbm.W_m.stride(1) != 1:
+                # the C ABI has one leading dimension for W and W_m: re-home W_m with W's pitch (values kept)
+                m2 = torch.empty_strided(tuple(W.shape), tuple(W.stride()), dtype=torch.float32, device=W.device)
+                m2.copy_(rbm.W_m)
+                rbm.W_m = m2
             d.W_m, d.hb_m, d.vb_m = rbm.W_m.data_ptr(), rbm.hb_m.data_ptr(), rbm.vb_m.data_ptr()
         groups = list(getattr(rbm, "softmax_groups", None) or [])
         if len(groups) > N.MAX_GROUPS:

@@ -20,6 +20,12 @@ import torch.nn as nn
 from imdbn import engine as _E
 
 
+def _row_pitch(h: int) -> int:
+    """Row pitch in elements: H rounded up to 32 floats (128 B) when that costs < 7 % extra memory."""
+    p = (h + 31) // 32 * 32
+    return p if (p - h) * 16 <= h else h
+
+
 def _step(T=1.0, sigma=0.0, eta=0.0, sample_h=False, vmode=0, clamp=True) -> dict:
     return {"T": float(T), "sigma": float(sigma), "eta": float(eta), "sample_h": bool(sample_h),
             "vmode": int(vmode), "clamp": bool(clamp)}
@@ -54,13 +60,17 @@ class RBM(nn.Module):
         self.softmax_groups = softmax_groups or []
 
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")      # rbm.py:69
-        self.W = nn.Parameter(
-            torch.randn(self.num_visible, self.num_hidden, device=device) / math.sqrt(max(1, self.num_visible)),
-            requires_grad=False)
+        # Same law as the reference (randn / sqrt(V), rbm.py:70-72).  On the GPU the rows of W and W_m are
+        # allocated with a pitch padded to 128 B: shape, values and semantics are unchanged (W is a [V,H]
+        # view with stride (pitch, 1)), but every 512-B row segment the kernels touch is cache-line aligned
+        # (H = 1500 would otherwise straddle 5 lines instead of 4: ~25 % over-fetch, profiles/r01_pmc_*).
+        pitch = _row_pitch(self.num_hidden) if device.type == "cuda" else self.num_hidden
+        w_full = torch.randn(self.num_visible, pitch, device=device) / math.sqrt(max(1, self.num_visible))
+        self.W = nn.Parameter(w_full[:, :self.num_hidden], requires_grad=False)
         self.hid_bias = nn.Parameter(torch.zeros(self.num_hidden, device=device), requires_grad=False)
         self.vis_bias = nn.Parameter(torch.zeros(self.num_visible, device=device), requires_grad=False)
         # momentum buffers: plain attributes, exactly as in the reference (rbm.py:77-79)
-        self.W_m = torch.zeros_like(self.W)
+        self.W_m = torch.zeros(self.num_visible, pitch, device=device)[:, :self.num_hidden]
         self.hb_m = torch.zeros_like(self.hid_bias)
         self.vb_m = torch.zeros_like(self.vis_bias)
 

@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--ksplit-up", type=int, default=0)
     ap.add_argument("--ksplit-down", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
+    ap.add_argument("--force-dp", action="store_true", help="take the stats/all-reduce/apply path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -82,8 +83,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as ge
@@ -102,8 +104,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    if world > 1:
-        E.dp.enable()
+    if world > 1 or args.force_dp:
+        E.dp.enable(force=args.force_dp)
 
     torch.manual_seed(0)
     rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
@@ -181,7 +183,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
 
 

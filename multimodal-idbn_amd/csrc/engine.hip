@@ -679,8 +679,11 @@ int imdbn_rbm_apply_delta(const imdbn_rbm_desc* d, const float* packed, int glob
     a.lr = o->lr; a.mom = o->momentum; a.wd = o->weight_decay; a.n = (float)global_B;
     a.sparsity = o->sparsity; a.target = o->sparsity_target; a.loss_out = loss_out;
     const int64_t total = (int64_t)d->V * d->H;
-    const int grid = (int)std::max<int64_t>(std::min<int64_t>((total + 255) / 256, 4096), cdiv(std::max(d->V, d->H), 256));
-    hipLaunchKernelGGL(apply_delta, dim3(grid), dim3(256), 0, S(stream), a);
+    const bool vec4 = d->H % 4 == 0 && d->ldw % 4 == 0 && ((((uintptr_t)d->W) | ((uintptr_t)d->W_m) | ((uintptr_t)packed)) & 15) == 0;
+    const int64_t items = vec4 ? total / 4 : total;
+    const int grid = (int)std::max<int64_t>(std::min<int64_t>((items + 255) / 256, 8192), cdiv(std::max(d->V, d->H), 256));
+    if (vec4) hipLaunchKernelGGL(apply_delta<true>, dim3(grid), dim3(256), 0, S(stream), a);
+    else      hipLaunchKernelGGL(apply_delta<false>, dim3(grid), dim3(256), 0, S(stream), a);
     HIPCHK(hipGetLastError());
     return 0;
 }

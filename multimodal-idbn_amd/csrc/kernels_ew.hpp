@@ -439,18 +439,34 @@ struct ApplyArgs {
     float* hid_bias; float* hb_m; float* vis_bias; float* vb_m;
     float lr, mom, wd, n; int sparsity; float target; float* loss_out;
 };
+// grid.x >= ceil(max(V,H)/256); VEC4: H % 4 == 0 and 16-B aligned rows of W, W_m and packed.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void apply_delta(const ApplyArgs a) {
-    const int64_t total = (int64_t)a.V * a.H;
+    const int hq = VEC4 ? a.H / 4 : a.H;                         // work items per row
+    const int64_t total = (int64_t)a.V * hq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t row = i / a.H, col = i - row * a.H;
-        const int64_t idx = row * a.ldw + col;
-        const float wold = a.W[idx];
-        float m = a.Wm[idx] * a.mom;
-        m = m + a.lr * (a.packed[i] / a.n - a.wd * wold);
-        a.Wm[idx] = m;
-        a.W[idx] = wold + m;
+        const int row = (int)(i / hq), q = (int)(i - (int64_t)row * hq);
+        if constexpr (VEC4) {
+            const int64_t idx = (int64_t)row * a.ldw + 4 * q;
+            const float4 d = *reinterpret_cast<const float4*>(a.packed + (int64_t)row * a.H + 4 * q);
+            const float4 w0 = *reinterpret_cast<const float4*>(a.W + idx);
+            float4 m = *reinterpret_cast<const float4*>(a.Wm + idx);
+            m.x = m.x * a.mom; m.x = m.x + a.lr * (d.x / a.n - a.wd * w0.x);
+            m.y = m.y * a.mom; m.y = m.y + a.lr * (d.y / a.n - a.wd * w0.y);
+            m.z = m.z * a.mom; m.z = m.z + a.lr * (d.z / a.n - a.wd * w0.z);
+            m.w = m.w * a.mom; m.w = m.w + a.lr * (d.w / a.n - a.wd * w0.w);
+            *reinterpret_cast<float4*>(a.Wm + idx) = m;
+            *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);
+        } else {
+            const int64_t idx = (int64_t)row * a.ldw + q;
+            const float wold = a.W[idx];
+            float m = a.Wm[idx] * a.mom;
+            m = m + a.lr * (a.packed[(int64_t)row * a.H + q] / a.n - a.wd * wold);
+            a.Wm[idx] = m;
+            a.W[idx] = wold + m;
+        }
     }
-    const float* tail = a.packed + total;
+    const float* tail = a.packed + (int64_t)a.V * a.H;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x * 256 < (unsigned)max(a.V, a.H)) {
         if (i < a.H) {

@@ -13,28 +13,33 @@ import torch
 
 _group = None
 _enabled = False
+_force = False
 
 
-def enable(group=None):
-    """Turn on data-parallel updates (requires an initialised torch.distributed)."""
-    global _group, _enabled
+def enable(group=None, force: bool = False):
+    """Turn on data-parallel updates (requires an initialised torch.distributed).
+
+    ``force=True`` takes the stats -> all-reduce -> apply path even with a single rank (used to
+    exercise the RCCL path on a one-GPU box)."""
+    global _group, _enabled, _force
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("imdbn.engine.dp.enable(): torch.distributed is not initialised")
     _group = group
     _enabled = True
+    _force = bool(force)
 
 
 def disable():
-    global _group, _enabled
-    _group, _enabled = None, False
+    global _group, _enabled, _force
+    _group, _enabled, _force = None, False, False
 
 
 def active() -> bool:
     if not _enabled:
         return False
     import torch.distributed as dist
-    return dist.is_initialized() and dist.get_world_size(_group) > 1
+    return dist.is_initialized() and (dist.get_world_size(_group) > 1 or _force)
 
 
 def world_size() -> int:

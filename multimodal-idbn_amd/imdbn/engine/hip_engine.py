@@ -238,6 +238,16 @@ class HipEngine:
     def packed_floats(self, V, H) -> int:
         return int(self._lib.imdbn_packed_delta_floats(V, H))
 
+    def packed_buffer(self, rbm) -> torch.Tensor:
+        """Reusable all-reduce buffer for this RBM's shape (every entry but the <=3 pad floats is rewritten by
+        cd_stats, so no per-step zeroing)."""
+        W = rbm.W.data
+        key = ("packed", W.device, W.shape[0], W.shape[1])
+        buf = self._ws.get(key)
+        if buf is None:
+            buf = self._ws[key] = torch.zeros(self.packed_floats(W.shape[0], W.shape[1]), device=W.device)
+        return buf
+
     def cd_stats(self, rbm, data, cd_k, rng, out: Optional[torch.Tensor] = None):
         d = self._desc(rbm, False)
         x = _f32c(data, "data")

@@ -146,7 +146,8 @@ class RBM(nn.Module):
             B = x.size(0)
             if isinstance(rng, _E.PhiloxRng):
                 rng.row0 = dp.rank() * B
-            packed = eng.cd_stats(self, x, CD, rng)
+            buf = eng.packed_buffer(self) if hasattr(eng, "packed_buffer") else None
+            packed = eng.cd_stats(self, x, CD, rng, out=buf)
             dp.all_reduce_sum(packed)
             return eng.apply_delta(self, packed, B * dp.world_size(), lr, mom)
         return eng.cd_step(self, x, lr, mom, CD, rng)

@@ -234,3 +234,31 @@ def test_pickle_roundtrip_and_reference_pickle(tmp_path):
     with open(p, "rb") as f:
         back = pickle.load(f)["layers"][0]
     assert torch.equal(back.W.data, jr.W.data) and set(vars(back)) == set(vars(jr))
+
+
+def test_dp_path_over_rccl_world1_equals_fused_update():
+    """stats -> torch.distributed all_reduce (backend nccl = RCCL) -> apply on the GPU, single rank:
+    must reproduce the fused update (same draws, same arithmetic up to summation order)."""
+    import socket
+    import torch.distributed as dist
+    from imdbn import engine as E
+    r1, st, g = _mk(512, 200, None, seed=21, sparsity=True, sparsity_factor=0.1)
+    r2, _, _ = _mk(512, 200, None, seed=21, sparsity=True, sparsity_factor=0.1)
+    X = (g.random((64, 512), dtype=F32) > 0.7).astype(F32)
+    with E.use_rng(E.PhiloxRng(seed=8)):
+        l1 = r1.train_epoch(P.T(X, DEV), 3, 10, CD=1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        E.dp.enable(force=True)
+        with E.use_rng(E.PhiloxRng(seed=8)):
+            l2 = r2.train_epoch(P.T(X, DEV), 3, 10, CD=1)
+    finally:
+        E.dp.disable()
+        dist.destroy_process_group()
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r2, k)), P.N(getattr(r1, k)), 1e-5, "dp " + k, atol=1e-7)
+    assert abs(float(l1) - float(l2)) < 1e-6

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--ksplit-down", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     ap.add_argument("--force-dp", action="store_true", help="take the stats/all-reduce/apply path even with one rank")
+    ap.add_argument("--no-k3-events", action="store_true", help="do not bracket K3 with HIP events in the timed region")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +128,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    if world == 1:
+    if world == 1 and not args.no_k3_events:
         eng.profile(True)
     t0 = time.perf_counter()
     for i in range(args.steps):

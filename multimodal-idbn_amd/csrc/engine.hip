@@ -53,6 +53,7 @@ struct Prof {
     bool on = false;
     std::vector<hipEvent_t> ev;   // pairs
     size_t used = 0;
+    unsigned calls = 0;           // only every 4th update launch is bracketed: the event records perturb the stream
 } g_prof;
 
 // ---- split-K plan --------------------------------------------------------------------------
@@ -319,8 +320,10 @@ int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_
     return 0;
 }
 
+int launch_bias(Ctx& c, const BiasArgs& b);
+
 int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms, const int* vpos_flag, int vneg_terms,
-                 float n, float* delta) {
+                 float n, float* delta, const BiasArgs* bias = nullptr) {
     const Layout& L = c.L;
     AssocArgs a;
     memset(&a, 0, sizeof(a));
@@ -332,7 +335,7 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
     a.vts = (int64_t)L.V * L.Bp; a.hts = (int64_t)L.H * L.Bp; a.Bp = L.Bp;
     a.lr = o->lr; a.mom = o->momentum; a.wd = o->weight_decay; a.n = n;
     a.delta = delta;
-    const bool prof = g_prof.on && !mode_stats && g_prof.used + 2 <= g_prof.ev.size();
+    const bool prof = g_prof.on && !mode_stats && (g_prof.calls++ % 4 == 0) && g_prof.used + 2 <= g_prof.ev.size();
     if (prof) HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], c.s));
     // fast path: every W / W_m / delta row start 16-B aligned -> float4 weight tiles, LDS-staged planes
     const bool fast = L.Bp == 64 && L.H % 4 == 0 && L.H >= 4 && c.d->ldw % 4 == 0 && (((uintptr_t)c.d->W) & 15) == 0 &&
@@ -350,11 +353,19 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int nh = cdiv(L.H, 128), nv = cdiv(L.V, 128);
         const int tpb = std::max(1, cdiv(nh * nv, std::max(cus, 1)));
-        dim3 g(nh, cdiv(nv, tpb));
-#define LAUNCH_K3(M, HTV) hipLaunchKernelGGL((assoc_update_planes<M, HTV>), g, dim3(256), 0, c.s, f, tpb)
+        // + one extra block row for the bias / loss update when the caller wants it fused
+        const int brows = bias ? (nh >= 2 ? 1 : 2) : 0;     // >= 2 blocks: one reduces the loss, the rest stride the biases
+        BiasArgs bz;
+        memset(&bz, 0, sizeof(bz));
+        const BiasArgs& bb = bias ? *bias : bz;
+        dim3 g(nh, cdiv(nv, tpb) + brows);
+#define LAUNCH_K3(M, HTV) hipLaunchKernelGGL((assoc_update_planes<M, HTV>), g, dim3(256), 0, c.s, f, tpb, bb, brows)
         if (c.rt == 3) { if (mode_stats) LAUNCH_K3(1, 3); else LAUNCH_K3(0, 3); }
         else           { if (mode_stats) LAUNCH_K3(1, 1); else LAUNCH_K3(0, 1); }
 #undef LAUNCH_K3
+        HIPCHK(hipGetLastError());
+        if (prof) { HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], c.s)); g_prof.used += 2; }
+        return 0;
     } else {
         dim3 grid(cdiv(L.H, 128), cdiv(L.V, 64));
         if (c.rt == 3) {
@@ -367,6 +378,7 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
     }
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], c.s)); g_prof.used += 2; }
+    if (bias) CHK(launch_bias(c, *bias));          // generic K3: bias update as its own launch
     return 0;
 }
 
@@ -411,7 +423,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o) {
     return 0;
 }
 
-int launch_bias(Ctx& c, const imdbn_cd_opts* o, bool sparsity, float n, float* loss_out) {
+BiasArgs make_bias(Ctx& c, const imdbn_cd_opts* o, bool sparsity, float n, float* loss_out) {
     const Layout& L = c.L;
     BiasArgs b;
     memset(&b, 0, sizeof(b));
@@ -420,7 +432,11 @@ int launch_bias(Ctx& c, const imdbn_cd_opts* o, bool sparsity, float n, float* l
     b.P = L.P; b.lr = o->lr; b.mom = o->momentum; b.n = n;
     b.sparsity = sparsity ? 1 : 0; b.target = o->sparsity_target;
     b.loss_part = L.loss_part; b.n_loss = n_loss_used(c, false); b.loss_den = n * (float)L.V; b.loss_out = loss_out;
-    hipLaunchKernelGGL(bias_update, dim3(cdiv(std::max(L.V, L.H), 256) + 1), dim3(256), 0, c.s, b);
+    return b;
+}
+
+int launch_bias(Ctx& c, const BiasArgs& b) {
+    hipLaunchKernelGGL(bias_update, dim3(cdiv(std::max(c.L.V, c.L.H), 256) + 1), dim3(256), 0, c.s, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -534,6 +550,7 @@ int imdbn_profile_enable(int on) {
     }
     g_prof.on = on != 0;
     g_prof.used = 0;
+    g_prof.calls = 0;
     return 0;
 }
 
@@ -639,8 +656,8 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
     CHK(setup(c, B, ws, ws_bytes));
     CHK(cd_phases(c, data, ldd, o));
     CHK(c.rng.finish());
-    CHK(launch_assoc(c, 0, o, c.nw == 1 ? 1 : 0, c.L.flags, 1, (float)B, nullptr));
-    CHK(launch_bias(c, o, o->sparsity != 0, (float)B, loss_out));
+    const BiasArgs bias = make_bias(c, o, o->sparsity != 0, (float)B, loss_out);
+    CHK(launch_assoc(c, 0, o, c.nw == 1 ? 1 : 0, c.L.flags, 1, (float)B, nullptr, &bias));
     return 0;
 }
 
@@ -746,8 +763,8 @@ int imdbn_rbm_clamped_step(const imdbn_rbm_desc* d, const float* v_known, const 
         CHK(prop(c, true, OpIn{L.vis_rm[1], o->sample_v ? 1 : c.rt, nullptr}, f));
     }
     CHK(c.rng.finish());
-    CHK(launch_assoc(c, 0, o, c.rt, nullptr, o->sample_v ? 1 : c.rt, (float)B, nullptr));
-    CHK(launch_bias(c, o, false, (float)B, loss_out));
+    const BiasArgs bias = make_bias(c, o, false, (float)B, loss_out);
+    CHK(launch_assoc(c, 0, o, c.rt, nullptr, o->sample_v ? 1 : c.rt, (float)B, nullptr, &bias));
     return 0;
 }
 

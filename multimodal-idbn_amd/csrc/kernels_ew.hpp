@@ -384,32 +384,39 @@ __device__ __forceinline__ double loss_total_256(const float* part, int n, doubl
     return sh[0];
 }
 
-// grid = ceil(max(V,H)/256) + 1: the LAST block only reduces the squared-error partials.
-__global__ __launch_bounds__(256) void bias_update(const BiasArgs a) {
-    __shared__ double sh[256];
-    if (blockIdx.x == gridDim.x - 1) {
+// Work of `nblk` 256-thread blocks: block `blk` == nblk-1 reduces the squared-error partials, the others
+// stride over the bias vectors.  Used by the stand-alone kernel and by the extra block row of K3.
+__device__ __forceinline__ void bias_work(const BiasArgs& a, int blk, int nblk, double* sh) {
+    if (blk == nblk - 1) {
         if (a.loss_out) {
             const double t = loss_total_256(a.loss_part, a.n_loss, sh);
             if (threadIdx.x == 0) a.loss_out[0] = (float)(t / (double)a.loss_den);      // rbm.py:226
         }
         return;
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.H) {
-        const float sp = sum_parts(a.hpos, a.P, a.H, i), sn = sum_parts(a.hneg, a.P, a.H, i);
-        float m = a.hb_m[i] * a.mom;
-        m = m + (a.lr * (sp - sn)) / a.n;                                   // rbm.py:216
-        if (a.sparsity) m = m + (-a.lr) * (sp / a.n - a.target);           // rbm.py:218-219
-        a.hb_m[i] = m;
-        a.hid_bias[i] += m;
+    for (int i = blk * 256 + threadIdx.x; i < max(a.V, a.H); i += (nblk - 1) * 256) {
+        if (i < a.H) {
+            const float sp = sum_parts(a.hpos, a.P, a.H, i), sn = sum_parts(a.hneg, a.P, a.H, i);
+            float m = a.hb_m[i] * a.mom;
+            m = m + (a.lr * (sp - sn)) / a.n;                                   // rbm.py:216
+            if (a.sparsity) m = m + (-a.lr) * (sp / a.n - a.target);           // rbm.py:218-219
+            a.hb_m[i] = m;
+            a.hid_bias[i] += m;
+        }
+        if (i < a.V) {
+            const float sp = sum_parts(a.vpos, a.P, a.V, i), sn = sum_parts(a.vneg, a.P, a.V, i);
+            float m = a.vb_m[i] * a.mom;
+            m = m + (a.lr * (sp - sn)) / a.n;                                   // rbm.py:223
+            a.vb_m[i] = m;
+            a.vis_bias[i] += m;
+        }
     }
-    if (i < a.V) {
-        const float sp = sum_parts(a.vpos, a.P, a.V, i), sn = sum_parts(a.vneg, a.P, a.V, i);
-        float m = a.vb_m[i] * a.mom;
-        m = m + (a.lr * (sp - sn)) / a.n;                                   // rbm.py:223
-        a.vb_m[i] = m;
-        a.vis_bias[i] += m;
-    }
+}
+
+// grid = ceil(max(V,H)/256) + 1
+__global__ __launch_bounds__(256) void bias_update(const BiasArgs a) {
+    __shared__ double sh[256];
+    bias_work(a, blockIdx.x, gridDim.x, sh);
 }
 
 // ---- data-parallel split ------------------------------------------------------------------

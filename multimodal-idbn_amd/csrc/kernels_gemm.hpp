@@ -659,8 +659,16 @@ __device__ __forceinline__ void k3_mfma(f32x16 (&acc)[4], const char* sH, const 
 // the weight stream never waits on a dependent load.
 // Requires Bp == 64 (one batch chunk) and 16-B aligned weight rows; otherwise the generic kernel runs.
 template <int MODE, int HT>
-__global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block) {
+__global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block,
+                                                              const BiasArgs bias, int bias_rows) {
     __shared__ __attribute__((aligned(16))) char smem[K3_LDS_BYTES];      // 144 KB static (the CU has 160 KB)
+    // The last `bias_rows` block rows of the grid do the (tiny, independent) bias / loss update of
+    // rbm.py:216-226 instead of a dependent launch of their own: they only touch the bias vectors.
+    if (bias_rows > 0 && (int)blockIdx.y >= (int)gridDim.y - bias_rows) {
+        bias_work(bias, (blockIdx.y - (gridDim.y - bias_rows)) * gridDim.x + blockIdx.x, bias_rows * gridDim.x,
+                  reinterpret_cast<double*>(smem));
+        return;
+    }
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, kh = l >> 5;
     const int h0 = blockIdx.x * 128;
     const int tile0 = blockIdx.y * tiles_per_block;

@@ -24,6 +24,7 @@ thread_local char g_err[512] = "";
 int g_ks_up = 0, g_ks_down = 0;
 bool g_no_fast_k3 = false;
 bool g_no_fast_k1 = false;
+bool g_no_fused_up = false;
 int g_dbg = 0;    // tuning/testing: force the generic K3
 
 int fail(int code, const char* fmt, ...) {
@@ -124,7 +125,7 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.cs_hneg = (float*)take((size_t)L.P * H * 4);
     L.cs_vpos = (float*)take((size_t)L.P * V * 4);
     L.cs_vneg = (float*)take((size_t)L.P * V * 4);
-    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 32) * (L.Bp / 64)) + IMDBN_MAX_GROUPS;
+    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 32) * (L.Bp / 64)) + IMDBN_MAX_GROUPS * (L.Bp / 64);
     L.loss_part = (float*)take((size_t)L.n_loss_slots * 4);
     L.bytes = off;
     return L;
@@ -250,6 +251,18 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     base_finish_args(c, up, f);
     if (f.T < 1e-6f) f.T = 1e-6f;                           // max(1e-6, T)  rbm.py:92,96
     const int mb = L.Bp / 64;
+    if (up && L.Vpad <= 1024 && !g_no_fused_up) {
+        // short K: fused GEMM + epilogue, no split-K slabs (one launch per half step of a chain)
+        dim3 grid(cdiv(L.H, 32), 1, mb);
+        const int64_t ats = (int64_t)L.Bp * L.Vpad;
+        f.dbg = 0;
+        if (c.nw == 3)
+            hipLaunchKernelGGL(gemm_up_fused<3>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, f);
+        else
+            hipLaunchKernelGGL(gemm_up_fused<1>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, f);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (up) {
         const int64_t ats = (int64_t)L.Bp * L.Vpad;
         const bool fast = L.up4 && d->ldw % 4 == 0 && (((uintptr_t)d->W) & 15) == 0;
@@ -274,7 +287,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
         f.dbg = g_dbg;
         const int64_t ats = (int64_t)L.Bp * L.Hpad;
         const bool vec4 = (d->ldw % 4 == 0) && (((uintptr_t)d->W & 15) == 0) && (L.H % 4 == 0) && L.H >= 4;
-        if ((int)(grid.x * grid.z) + IMDBN_MAX_GROUPS > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
+        if ((int)((grid.x + IMDBN_MAX_GROUPS) * grid.z) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
 #define LAUNCH_DOWN(NW, V4) \
     hipLaunchKernelGGL((gemm_down_fused<NW, V4>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f)
         if (c.nw == 3) { if (vec4) LAUNCH_DOWN(3, true); else LAUNCH_DOWN(3, false); }
@@ -282,7 +295,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
 #undef LAUNCH_DOWN
         HIPCHK(hipGetLastError());
         if (f.n_groups > 0 && !f.logits_only) {
-            hipLaunchKernelGGL(finish_groups, dim3(f.n_groups), dim3(64), 0, c.s, f, (int)(grid.x * grid.z));
+            hipLaunchKernelGGL(finish_groups, dim3(f.n_groups, L.Bp / 64), dim3(256), 0, c.s, f, (int)(grid.x * grid.z));
             HIPCHK(hipGetLastError());
         }
         return 0;
@@ -291,18 +304,18 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     if (f.n_groups > 0 && !f.logits_only && !f.out_prob) f.out_prob = L.f_vp, f.ld_prob = L.V;
     if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
     dim3 fgrid(cdiv(f.N, 64), L.P);
-    if ((int)(fgrid.x * fgrid.y) + IMDBN_MAX_GROUPS > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
+    if ((int)(fgrid.x * fgrid.y) + IMDBN_MAX_GROUPS * (L.Bp / 64) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
     hipLaunchKernelGGL(finish, fgrid, dim3(256), 0, c.s, f);
     HIPCHK(hipGetLastError());
     if (f.n_groups > 0 && !f.logits_only) {
-        hipLaunchKernelGGL(finish_groups, dim3(f.n_groups), dim3(64), 0, c.s, f, (int)(fgrid.x * fgrid.y));
+        hipLaunchKernelGGL(finish_groups, dim3(f.n_groups, L.Bp / 64), dim3(256), 0, c.s, f, (int)(fgrid.x * fgrid.y));
         HIPCHK(hipGetLastError());
     }
     return 0;
 }
 int n_loss_used(const Ctx& c, bool up) {
     if (up) return cdiv(c.L.H, 64) * c.L.P;
-    return cdiv(c.L.V, 32) * (c.L.Bp / 64) + c.d->n_groups;      // fused K2: one partial per block
+    return (cdiv(c.L.V, 32) + c.d->n_groups) * (c.L.Bp / 64);    // fused K2: one partial per block (+ per group block)
 }
 
 // caller fp32 tensor -> operand forms in the workspace
@@ -539,6 +552,7 @@ int imdbn_set_option(const char* name, int value) {
     else if (!strcmp(name, "generic_k3")) g_no_fast_k3 = value != 0;
     else if (!strcmp(name, "dbg")) g_dbg = value;
     else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
+    else if (!strcmp(name, "no_fused_up")) g_no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);
     return 0;
 }

@@ -199,14 +199,16 @@ __global__ __launch_bounds__(256) void finish(const FinishArgs a) {
     }
 }
 
-// One block (64 threads) per softmax group.  Phase 1: thread = batch row: softmax over the group's
-// logits (left in out_prob by `finish`), mu-pull, clamp-mix, categorical.  Phase 2: thread = column:
-// operand forms, column sums, squared error (sequential over rows: deterministic).
-__global__ __launch_bounds__(64) void finish_groups(const FinishArgs a, int loss_slot0) {
-    __shared__ float sh[64];
-    const int g = blockIdx.x, s = a.gs[g], e = a.ge[g], wd = e - s;
-    const int lane = threadIdx.x;
-    for (int b = lane; b < a.B; b += 64) {
+// Softmax groups: grid = (n_groups, Bp/64), block = 256.  Phase 1: thread = batch row (64 per block):
+// softmax over the group's logits (left in out_prob by the main epilogue), mu-pull, clamp-mix,
+// categorical.  Phase 2: thread = (column, 8-row octet): operand forms, column-sum partial of that
+// octet (same [Bp/8][N] layout as the main epilogue), squared error.
+__global__ __launch_bounds__(256) void finish_groups(const FinishArgs a, int loss_slot0) {
+    __shared__ float sh[256];
+    const int g = blockIdx.x, rb = blockIdx.y, s = a.gs[g], e = a.ge[g], wd = e - s;
+    const int tid = threadIdx.x;
+    const int b = rb * 64 + tid;
+    if (tid < 64 && b < a.B) {
         float* row = a.out_prob + (int64_t)b * a.ld_prob + s;
         float mx = -INFINITY;
         for (int j = 0; j < wd; ++j) mx = fmaxf(mx, row[j]);
@@ -222,7 +224,6 @@ __global__ __launch_bounds__(64) void finish_groups(const FinishArgs a, int loss
                 thr = draw_uniform(cs, b, 0);
             }
         }
-        // first pass: probabilities (and total of the clamped weights for inverse-CDF)
         for (int j = 0; j < wd; ++j) {
             const int col = s + j;
             float p = expf(row[j] - mx) / sum;
@@ -269,41 +270,38 @@ __global__ __launch_bounds__(64) void finish_groups(const FinishArgs a, int loss
     __threadfence_block();
     __syncthreads();
     float lsum = 0.f;
-    for (int j = lane; j < wd; j += 64) {
-        const int col = s + j;
+    for (int it = tid; it < wd * 8; it += 256) {
+        const int j = it % wd, oct = it / wd;
+        const int col = s + j, b0 = rb * 64 + oct * 8;
+        float xp[8], xf[8];
         float csum = 0.f;
-        for (int b0 = 0; b0 < a.Bp; b0 += 8) {
-            float xp[8], xf[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int b = b0 + i;
-                const bool ok = b < a.B;
-                xp[i] = ok ? a.out_prob[(int64_t)b * a.ld_prob + col] : 0.f;
-                xf[i] = (ok && a.out_final) ? a.out_final[(int64_t)b * a.ld_final + col] : 0.f;
-                if (ok) {
-                    csum += (a.colsum_src == 2 ? xf[i] : xp[i]);
-                    if (a.loss_ref) {
-                        const float d = a.loss_ref[(int64_t)b * a.ld_ref + col] - (a.loss_src == 2 ? xf[i] : xp[i]);
-                        lsum += d * d;
-                    }
-                }
+        for (int i = 0; i < 8; ++i) {
+            const int bb = b0 + i;
+            const bool ok = bb < a.B;
+            const int bc = min(bb, a.B - 1);
+            const float pv = a.out_prob[(int64_t)bc * a.ld_prob + col];
+            const float fv = a.out_final ? a.out_final[(int64_t)bc * a.ld_final + col] : 0.f;
+            const float rv = a.loss_ref ? a.loss_ref[(int64_t)bc * a.ld_ref + col] : 0.f;
+            xp[i] = ok ? pv : 0.f;
+            xf[i] = ok ? fv : 0.f;
+            if (ok) {
+                csum += (a.colsum_src == 2 ? fv : pv);
+                const float d = rv - (a.loss_src == 2 ? fv : pv);
+                lsum += a.loss_ref ? d * d : 0.f;
             }
-            if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
-            if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
         }
-        if (a.colsum_part) {
-            const int P = a.Bp / 8;
-            a.colsum_part[col] = csum;
-            for (int p = 1; p < P; ++p) a.colsum_part[(int64_t)p * a.N + col] = 0.f;
-        }
+        if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
+        if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
+        if (a.colsum_part) a.colsum_part[(int64_t)(b0 >> 3) * a.N + col] = csum;
     }
     if (a.loss_part) {
-        sh[lane] = lsum;
+        sh[tid] = lsum;
         __syncthreads();
-        if (lane == 0) {
+        if (tid == 0) {
             float t = 0.f;
-            for (int i = 0; i < 64; ++i) t += sh[i];
-            a.loss_part[loss_slot0 + g] = t;
+            for (int i = 0; i < 256; ++i) t += sh[i];
+            a.loss_part[loss_slot0 + g * gridDim.y + rb] = t;
         }
     }
 }

@@ -315,7 +315,7 @@ struct DownOperands {
     uint4 av[NA][2];
 };
 
-template <int NW, bool VEC4, int NA>
+template <bool UP, int NW, bool VEC4, int NA>
 __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int64_t ldw, int K, int N,
                                                 const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
                                                 const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33]) {
@@ -327,13 +327,17 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-    const float* wrow = W + (int64_t)min(n0 + r, N - 1) * ldw;
+    // UP: W is [K][N] (the tile's column, 8 K rows = 8 dword loads); DOWN: W is [N][K] (8 contiguous floats)
+    const float* wrow = UP ? (W + min(n0 + r, N - 1)) : (W + (int64_t)min(n0 + r, N - 1) * ldw);
     const int64_t arow0 = mb + r, arow1 = mb + 32 + r;
     auto load = [&](DownOperands<NA>& o, int kb) {
         const int kbc = min(kb, lda - 16);              // clamped: blocks past the end are loaded but never used
         const int k0 = kbc + 8 * hh;
         const int64_t ablk = (int64_t)(kbc >> 4) * fa.Bp;
-        if constexpr (VEC4) {
+        if constexpr (UP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.wv[j] = wrow[(int64_t)min(k0 + j, K - 1) * ldw];
+        } else if constexpr (VEC4) {
             const float4 x0 = *reinterpret_cast<const float4*>(wrow + min(k0, K - 4));
             const float4 x1 = *reinterpret_cast<const float4*>(wrow + min(k0 + 4, K - 4));
             o.wv[0] = x0.x; o.wv[1] = x0.y; o.wv[2] = x0.z; o.wv[3] = x0.w;
@@ -415,8 +419,22 @@ __global__ __launch_bounds__(256, 2) void gemm_down_fused(
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
     const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
-    if (na == 1) down_fused_body<NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
-    else         down_fused_body<NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
+    if (na == 1) down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
+    else         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
+}
+
+// K1 fused with its epilogue for SHORT visible dimensions (K = V <= 1024: joint RBM, chains): same
+// structure as gemm_down_fused with the [K][N] weight access; no split-K slabs, one launch per half step.
+template <int NW>
+__global__ __launch_bounds__(256, 2) void gemm_up_fused(
+    const float* __restrict__ W, int64_t ldw, int K, int N,
+    const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
+    const FinishArgs fa) {
+    __shared__ float red[4 * 32 * 64];
+    __shared__ float tile[64][33];
+    const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
+    if (na == 1) down_fused_body<true, NW, false, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
+    else         down_fused_body<true, NW, false, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
 }
 
 // ------------------------------------------------------------------------------------------

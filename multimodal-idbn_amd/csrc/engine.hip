@@ -200,6 +200,8 @@ int check_desc(const imdbn_rbm_desc* d, bool need_momentum) {
     for (int g = 0; g < d->n_groups; ++g) {
         if (d->group_start[g] < 0 || d->group_end[g] > d->V || d->group_start[g] >= d->group_end[g])
             return fail(IMDBN_E_INVALID, "softmax group %d = (%d,%d) outside [0,%d)", g, d->group_start[g], d->group_end[g], d->V);
+        if (d->group_end[g] - d->group_start[g] > GROUP_WMAX)
+            return fail(IMDBN_E_UNSUPPORTED, "softmax group %d is %d wide; at most %d supported", g, d->group_end[g] - d->group_start[g], GROUP_WMAX);
         for (int k = 0; k < g; ++k)
             if (d->group_start[g] < d->group_end[k] && d->group_start[k] < d->group_end[g])
                 return fail(IMDBN_E_UNSUPPORTED, "overlapping softmax groups %d and %d", k, g);

@@ -199,75 +199,59 @@ __global__ __launch_bounds__(256) void finish(const FinishArgs a) {
     }
 }
 
-// Softmax groups: grid = (n_groups, Bp/64), block = 256.  Phase 1: thread = batch row (64 per block):
-// softmax over the group's logits (left in out_prob by the main epilogue), mu-pull, clamp-mix,
-// categorical.  Phase 2: thread = (column, 8-row octet): operand forms, column-sum partial of that
-// octet (same [Bp/8][N] layout as the main epilogue), squared error.
+// Softmax groups (rbm.py:113-114,129-133): grid = (n_groups, Bp/64), block = 256, group width <= 256.
+//   stage : the block's 64 x width logits (left in out_prob by the main epilogue) -> LDS, coalesced
+//   rows  : thread = batch row: max, sum of exp, categorical index -- from LDS, no global traffic
+//   elems : thread = (column, 8-row octet): softmax value, mu-pull, clamp-mix, one-hot, all stores,
+//           column-sum partial of the octet ([Bp/8][N] layout of the main epilogue), squared error
+constexpr int GROUP_WMAX = 256;
+
 __global__ __launch_bounds__(256) void finish_groups(const FinishArgs a, int loss_slot0) {
+    __shared__ float sL[64][GROUP_WMAX + 1];
+    __shared__ float rmx[64], rsum[64];
+    __shared__ int ridx[64];
     __shared__ float sh[256];
     const int g = blockIdx.x, rb = blockIdx.y, s = a.gs[g], e = a.ge[g], wd = e - s;
     const int tid = threadIdx.x;
-    const int b = rb * 64 + tid;
-    if (tid < 64 && b < a.B) {
-        float* row = a.out_prob + (int64_t)b * a.ld_prob + s;
+    for (int it = tid; it < 64 * wd; it += 256) {
+        const int row = it / wd, j = it - row * wd;
+        const int bc = min(rb * 64 + row, a.B - 1);
+        sL[row][j] = a.out_prob[(int64_t)bc * a.ld_prob + s + j];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int b = min(rb * 64 + tid, a.B - 1);
         float mx = -INFINITY;
-        for (int j = 0; j < wd; ++j) mx = fmaxf(mx, row[j]);
+        for (int j = 0; j < wd; ++j) mx = fmaxf(mx, sL[tid][j]);
         float sum = 0.f;
-        for (int j = 0; j < wd; ++j) sum += expf(row[j] - mx);
-        // categorical over clamp(t,1e-8,1) where t = p (vmode 1) or mix(p) (vmode 2)
+        for (int j = 0; j < wd; ++j) sum += expf(sL[tid][j] - mx);
         int idx = -1;
-        float tot = 0.f, thr = 0.f;
         if (a.vmode != 0) {
             if (a.cat_tape) idx = a.cat_tape[(int64_t)g * a.B + b];
-            else {
+            else {   // PHILOX: inverse CDF over clamp(t,1e-8,1), t = p (vmode 1) or mix(p) (vmode 2)  (oracle/draws.py)
                 DrawSrc cs = a.cat_uni; cs.draw += g; cs.N = 1;
-                thr = draw_uniform(cs, b, 0);
-            }
-        }
-        for (int j = 0; j < wd; ++j) {
-            const int col = s + j;
-            float p = expf(row[j] - mx) / sum;
-            if (a.mu && col < a.Dz) p = (1.0f - a.eta) * p + a.eta * a.mu[(int64_t)b * a.ldmu + col];
-            row[j] = p;
-            if (a.vmode != 0 && idx < 0) {
-                float t = p;
-                if (a.vmode == 2 && a.clamp) {
-                    const float m = a.mask[(int64_t)b * a.ldk + col];
-                    t = p * (1.0f - m) + a.vk[(int64_t)b * a.ldk + col] * m;
+                const float thr = draw_uniform(cs, b, 0);
+                float tot = 0.f;
+                for (int pass = 0; pass < 2; ++pass) {
+                    float acc = 0.f;
+                    const float target = thr * tot;
+                    for (int j = 0; j < wd; ++j) {
+                        const int col = s + j;
+                        float t = expf(sL[tid][j] - mx) / sum;
+                        if (a.mu && col < a.Dz) t = (1.0f - a.eta) * t + a.eta * a.mu[(int64_t)b * a.ldmu + col];
+                        if (a.vmode == 2 && a.clamp) {
+                            const float m = a.mask[(int64_t)b * a.ldk + col];
+                            t = t * (1.0f - m) + a.vk[(int64_t)b * a.ldk + col] * m;
+                        }
+                        acc += fminf(fmaxf(t, 1e-8f), 1.0f);
+                        if (pass == 1 && acc > target) { idx = j; break; }
+                    }
+                    if (pass == 0) tot = acc; else if (idx < 0) idx = wd - 1;
                 }
-                tot += fminf(fmaxf(t, 1e-8f), 1.0f);
             }
         }
-        if (a.vmode != 0 && idx < 0) {              // PHILOX: inverse CDF (oracle/draws.py:categorical)
-            const float target = thr * tot;
-            float acc = 0.f;
-            idx = wd - 1;
-            for (int j = 0; j < wd; ++j) {
-                const int col = s + j;
-                float t = row[j];
-                if (a.vmode == 2 && a.clamp) {
-                    const float m = a.mask[(int64_t)b * a.ldk + col];
-                    t = t * (1.0f - m) + a.vk[(int64_t)b * a.ldk + col] * m;
-                }
-                acc += fminf(fmaxf(t, 1e-8f), 1.0f);
-                if (acc > target) { idx = j; break; }
-            }
-        }
-        if (a.out_final) {
-            for (int j = 0; j < wd; ++j) {
-                const int col = s + j;
-                const float p = row[j];
-                const float m = a.clamp ? a.mask[(int64_t)b * a.ldk + col] : 0.f;
-                const float kn = a.clamp ? a.vk[(int64_t)b * a.ldk + col] : 0.f;
-                float v;
-                if (a.vmode == 0) v = a.clamp ? (p * (1.0f - m) + kn * m) : p;
-                else if (a.vmode == 1) { const float o = (j == idx) ? 1.f : 0.f; v = a.clamp ? (o * (1.0f - m) + kn * m) : o; }
-                else v = (j == idx) ? 1.f : 0.f;
-                a.out_final[(int64_t)b * a.ld_final + col] = v;
-            }
-        }
+        rmx[tid] = mx; rsum[tid] = sum; ridx[tid] = idx;
     }
-    __threadfence_block();
     __syncthreads();
     float lsum = 0.f;
     for (int it = tid; it < wd * 8; it += 256) {
@@ -277,19 +261,27 @@ __global__ __launch_bounds__(256) void finish_groups(const FinishArgs a, int los
         float csum = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int bb = b0 + i;
+            const int row = oct * 8 + i, bb = b0 + i;
             const bool ok = bb < a.B;
             const int bc = min(bb, a.B - 1);
-            const float pv = a.out_prob[(int64_t)bc * a.ld_prob + col];
-            const float fv = a.out_final ? a.out_final[(int64_t)bc * a.ld_final + col] : 0.f;
+            float p = expf(sL[row][j] - rmx[row]) / rsum[row];
+            if (a.mu && col < a.Dz) p = (1.0f - a.eta) * p + a.eta * a.mu[(int64_t)bc * a.ldmu + col];
+            const float m = a.clamp ? a.mask[(int64_t)bc * a.ldk + col] : 0.f;
+            const float kn = a.clamp ? a.vk[(int64_t)bc * a.ldk + col] : 0.f;
             const float rv = a.loss_ref ? a.loss_ref[(int64_t)bc * a.ld_ref + col] : 0.f;
-            xp[i] = ok ? pv : 0.f;
-            xf[i] = ok ? fv : 0.f;
+            float v;
+            if (a.vmode == 0) v = a.clamp ? (p * (1.0f - m) + kn * m) : p;
+            else if (a.vmode == 1) { const float o = (j == ridx[row]) ? 1.f : 0.f; v = a.clamp ? (o * (1.0f - m) + kn * m) : o; }
+            else v = (j == ridx[row]) ? 1.f : 0.f;
             if (ok) {
-                csum += (a.colsum_src == 2 ? fv : pv);
-                const float d = rv - (a.loss_src == 2 ? fv : pv);
+                a.out_prob[(int64_t)bb * a.ld_prob + col] = p;
+                if (a.out_final) a.out_final[(int64_t)bb * a.ld_final + col] = v;
+                csum += (a.colsum_src == 2 ? v : p);
+                const float d = rv - (a.loss_src == 2 ? v : p);
                 lsum += a.loss_ref ? d * d : 0.f;
             }
+            xp[i] = ok ? p : 0.f;
+            xf[i] = ok ? v : 0.f;
         }
         if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
         if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);

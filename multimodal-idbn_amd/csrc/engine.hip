@@ -418,8 +418,8 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o) {
             FinishArgs f = new_finish();
             f.vmode = 1; f.uni = c.rng.floats(B, L.V);
             c.rng.cats(B, c.d->n_groups, &f.cat_tape, &f.cat_uni);
-            f.out_prob = L.f_vp; f.ld_prob = L.V;
-            f.out_final = L.f_v[1]; f.ld_final = L.V;
+            // the fp32 copies of v_prob / v are only read back by the softmax-group kernel (prop() supplies
+            // scratch for them when groups exist): without groups nobody needs them -> 5 MB of stores saved
             f.op.rm = L.vis_rm[1]; f.op.rm_terms = 1; f.rm_src = 2;
             f.op.tr = L.vis_tr[1]; f.op.tr_terms = 1; f.tr_src = 2;
             f.colsum_part = L.cs_vneg; f.colsum_src = 2;

@@ -676,6 +676,42 @@ __device__ __forceinline__ void k3_mfma(f32x16 (&acc)[4], const char* sH, const 
 // (one wave per SIMD, 512 registers).  Operand re-reads drop from ~120 MB to ~50 MB per launch and
 // the weight stream never waits on a dependent load.
 // Requires Bp == 64 (one batch chunk) and 16-B aligned weight rows; otherwise the generic kernel runs.
+// Wave-private staging of this wave's 32 visible rows of one plane (64 batch rows): 256 16-B chunks,
+// 4 per lane, loads first.  No block barrier: only this wave reads the slice (LDS ops of a wave are in order).
+__device__ __forceinline__ void k3_stage_wave(char* dst, const bf16_t* src, int v0w, int V, int Bp, bool negate) {
+    const int l = threadIdx.x & 63;
+    uint4 x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = l + 64 * q, row = i >> 3, c = i & 7;
+        x[q] = *reinterpret_cast<const uint4*>(src + (int64_t)min(v0w + row, V - 1) * Bp + 8 * c);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = l + 64 * q, row = i >> 3, c = i & 7;
+        uint4 v = x[q];
+        if (negate) { v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u; }
+        *reinterpret_cast<uint4*>(dst + row * K3_ROWB + 16 * c) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// MFMAs of one visible plane (single term, wave-private slice sVw) against HT hidden planes
+template <int HT>
+__device__ __forceinline__ void k3_mfma_wave(f32x16 (&acc)[4], const char* sH, const char* sVw, int r, int kh) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const uint4 af = *reinterpret_cast<const uint4*>(sVw + r * K3_ROWB + 32 * kb + 16 * kh);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int tb = 0; tb < HT; ++tb) {
+                const uint4 bf = *reinterpret_cast<const uint4*>(sH + tb * K3_PLANE + (t * 32 + r) * K3_ROWB + 32 * kb + 16 * kh);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af), as_frag(bf), acc[t], 0, 0, 0);
+            }
+    }
+}
+
 template <int MODE, int HT>
 __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block,
                                                               const BiasArgs bias, int bias_rows) {
@@ -718,7 +754,7 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
 
     char* sHp = smem;
     char* sHn = smem + 3 * K3_PLANE;
-    char* sV0 = smem + 6 * K3_PLANE;            // two visible-plane buffers, alternating
+    char* sVw = smem + 6 * K3_PLANE + w * (2 * 32 * K3_ROWB);     // this wave's two 32-row visible slices
 
     auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0) {
         if constexpr (MODE == 0) {
@@ -735,6 +771,7 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
     load_tile(wA, mA, tile0 * 128);                                     // weight stream starts first
     k3_stage<true, HT>(sHp, a.hpos, a.hts, h0, a.H, a.Bp, 0, false);    // hidden planes: once per block
     k3_stage<true, HT>(sHn, a.hneg, a.hts, h0, a.H, a.Bp, 0, false);
+    __syncthreads();                                                    // the ONLY block barrier: from here the waves run independently
 
     int vbuf = 0;
     auto tile = [&](int it, float4 (&wc)[16], float4 (&mc)[16], float4 (&wn)[16], float4 (&mn)[16]) {
@@ -744,15 +781,15 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        // positive then negative phase, one visible plane (term) at a time
+        // positive then negative phase, one visible plane (term) at a time, staged by this wave for itself
         for (int ph = 0; ph < 2; ++ph) {
             const int nt_ = ph ? nan_ : nap;
             for (int ta = 0; ta < nt_; ++ta) {
-                char* sVc = sV0 + vbuf * K3_PLANE;
-                k3_stage<false, 1>(sVc, (ph ? a.vneg : a.vpos) + ta * a.vts, 0, v0, a.V, a.Bp, 0, ph != 0);
-                __syncthreads();          // plane (and, first time, the hidden planes) visible to all waves
+                char* sVc = sVw + vbuf * (32 * K3_ROWB);
+                k3_stage_wave(sVc, (ph ? a.vneg : a.vpos) + ta * a.vts, v0 + 32 * w, a.V, a.Bp, ph != 0);
+                __builtin_amdgcn_wave_barrier();
                 if (ph == 0 && ta == 0 && it + 1 < n_my) load_tile(wn, mn, v0 + 128);     // next tile's weights
-                k3_mfma<HT, 1>(acc, ph ? sHn : sHp, sVc, w, r, kh);
+                k3_mfma_wave<HT>(acc, ph ? sHn : sHp, sVc, r, kh);
                 vbuf ^= 1;
             }
         }

@@ -5,7 +5,8 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
 timeout -k 10 500 python -m pytest tests -m gpu -q -x --timeout=300 > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest exit $?" | tee -a gpurun_out/pytest_gpu.log
+rc=$?; echo "pytest exit $rc" | tee -a gpurun_out/pytest_gpu.log
+if [ $rc -ge 124 ]; then tail -40 gpurun_out/pytest_gpu.log; echo "pytest was killed: no further GPU step in this call"; exit $rc; fi
 tail -40 gpurun_out/pytest_gpu.log
 timeout -k 10 120 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -3 gpurun_out/smoke.log
 timeout -k 10 200 python bench.py --steps 200 --warmup 20 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -2 gpurun_out/bench.log

@@ -160,5 +160,29 @@ int main() {
         run("rw4  K3 float4  240MB", 240, cold, [&](int b) { hipLaunchKernelGGL(rw4, dim3((H + 127) / 128, (V + 127) / 128), dim3(256), 0, 0, Wb[b], Mb[b]); });
         run("rwlin float4    240MB", 240, cold, [&](int b) { hipLaunchKernelGGL(rwlin, dim3(2048), dim3(256), 0, 0, (float4*)Wb[b], (float4*)Mb[b], n / 4); });
     }
+    // ---- sequence experiment: does W / W_m stay in the Infinity Cache across the kernels of one CD step?
+    // per iteration: 3 streaming reads of W (the three propagations) then the K3-shaped read-modify-write of W, W_m
+    {
+        auto seq = [&](bool with_rw, bool float4_rw) {
+            for (int i = 0; i < 3; ++i) {
+                for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(lin4, dim3(2048), dim3(256), 0, 0, (const float4*)Wb[0], n / 4, sink);
+                if (with_rw) { if (float4_rw) hipLaunchKernelGGL(rw4, dim3((H + 127) / 128, (V + 127) / 128), dim3(256), 0, 0, Wb[0], Mb[0]);
+                               else hipLaunchKernelGGL(rwlin, dim3(2048), dim3(256), 0, 0, (float4*)Wb[0], (float4*)Mb[0], n / 4); }
+            }
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < REP; ++i) {
+                for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(lin4, dim3(2048), dim3(256), 0, 0, (const float4*)Wb[0], n / 4, sink);
+                if (with_rw) { if (float4_rw) hipLaunchKernelGGL(rw4, dim3((H + 127) / 128, (V + 127) / 128), dim3(256), 0, 0, Wb[0], Mb[0]);
+                               else hipLaunchKernelGGL(rwlin, dim3(2048), dim3(256), 0, 0, (float4*)Wb[0], (float4*)Mb[0], n / 4); }
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            return 1e3 * ms / REP;
+        };
+        const double t0 = seq(false, false), t1 = seq(true, true), t2 = seq(true, false);
+        printf("sequence 3x read(W): %.1f us/iter ; + rw4(W,Wm): %.1f us (marginal %.1f us) ; + rwlin: %.1f us (marginal %.1f us)\n",
+               t0, t1, t1 - t0, t2, t2 - t0);
+    }
     return 0;
 }

@@ -28,6 +28,27 @@ for _p in (ROOT, os.path.join(ROOT, "multimodal-idbn_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+
+
+def _cpu_share() -> int:
+    """CPUs this process may actually use (cgroup v2 quota; a GPU box gives one GPU's share, e.g. 16 of 256)."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(q) // int(p))
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+# Thread pools sized to the visible 256 cpus overrun a 16-cpu cgroup quota: the spinning workers get the
+# whole cgroup throttled and the enqueue thread stalls for tens of ms (measured: one 77 ms stall in a 40 ms
+# timed region).  Size the pools to the share before torch / numpy start them.
+CPU_SHARE = _cpu_share()
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, CPU_SHARE)))
+os.environ.setdefault("OPENBLAS_NUM_THREADS", str(CPU_SHARE))
+os.environ.setdefault("MKL_NUM_THREADS", str(CPU_SHARE))
+
 V, H, B = 10000, 1500, 64
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
@@ -56,7 +77,12 @@ def cpu_baseline(max_seconds: float = 12.0, max_updates: int = 60):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "updates/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} CD-1 updates of the same 10000x1500 batch-64 workload, numpy/OpenBLAS oracle, "
-                      f"{os.cpu_count()} host cpus visible"}
+                      f"{os.cpu_count()} host cpus visible, cgroup share {CPU_SHARE}"}
+
+
+def _p50_max(t0, stamps):
+    d = sorted(1e6 * (b - a) for a, b in zip([t0] + stamps[:-1], stamps))
+    return [round(d[len(d) // 2], 1), round(d[-1], 1)] if d else None
 
 
 def main():
@@ -131,8 +157,10 @@ def main():
     if world == 1 and not args.no_k3_events:
         eng.profile(True)
     t0 = time.perf_counter()
+    stamps = []
     for i in range(args.steps):
         loss = step(i)
+        stamps.append(time.perf_counter())
     t_enq = time.perf_counter() - t0          # host time to enqueue all steps (== dt when host-bound)
     sync()
     dt = time.perf_counter() - t0
@@ -159,6 +187,7 @@ def main():
                        "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
                        "final_loss": float(loss)},
             "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
+            "host_enqueue_us_p50_max": _p50_max(t0, stamps),
             "frac_hbm_roofline_whole_step": ups * 16.0 * V * H / (HBM_PEAK_GBS * 1e9),
             "frac_bf16_mfma_roofline_whole_step": ups * 10.0 * B * V * H / (BF16_PEAK_TFLOPS * 1e12),
         }

@@ -17,6 +17,7 @@
 //   * No LDS staging of operands: the fragment shapes above make every global access either a
 //     128-B row segment per half-wave (W) or a 16-B piece of an L2-resident activation.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "kernels_ew.hpp"
 
@@ -712,6 +713,129 @@ __device__ __forceinline__ void k3_mfma_wave(f32x16 (&acc)[4], const char* sH, c
     }
 }
 
+// One block's stream of visible tiles for a fixed (NP, NN) = number of bf16 terms of the positive / negative
+// visible operand.  Per tile and wave the VMEM order is: [all NP+NN plane slices of this wave -> registers]
+// [next tile's W, W_m -> registers] ... [this tile's stores].  vmcnt retires in order, so a plane wait
+// placed after the weight prefetch would drain the prefetch; with this order the only waits are
+// "planes arrived" (weights stay in flight for the whole tile) and, implicitly, the previous tile's stores.
+// No conditional sits between a load and its wait (a divergent count makes the compiler wait for 0).
+template <int MODE, int HT, int NP, int NN>
+__device__ __attribute__((noinline)) void k3_body(const AssocPlanesArgs& a, char* smem, int bx, int by, int tiles_per_block) {
+    constexpr int P = NP + NN, PRE = P < 4 ? P : 4;     // planes staged in registers ahead of the weight prefetch
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, kh = l >> 5;
+    const int h0 = bx * 128;
+    const int tile0 = by * tiles_per_block;
+    const int n_vtiles = (a.V + 127) / 128;
+    const int n_my = min(tiles_per_block, n_vtiles - tile0);
+    const int colc = min(h0 + 4 * r, a.H - 4);
+    const bool cok = (h0 + 4 * r) < a.H;          // H % 4 == 0: a float4 is entirely inside or outside
+    const bool n_pow2 = (__float_as_uint(a.n) & 0x7fffffu) == 0u;      // d / n == d * (1/n) exactly
+    const float inv_n = 1.0f / a.n;
+
+    char* sHp = smem;
+    char* sHn = smem + 3 * K3_PLANE;
+    char* s0 = smem + 6 * K3_PLANE + w * (2 * 32 * K3_ROWB);     // this wave's two 32-row visible slices
+    char* s1 = s0 + 32 * K3_ROWB;
+
+    // `valid` false (no next tile): every row index collapses to the tile's first row -> the 16 loads hit the
+    // same two lines (no traffic), but the load COUNT stays fixed
+    auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0, bool valid) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = valid ? min(v0 + 32 * w + mfma_row(reg, l), a.V - 1) : tile0 * 128;
+                const int64_t idx = (int64_t)row * a.ldw + colc;
+                wo[reg] = *reinterpret_cast<const float4*>(a.W + idx);
+                mo[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
+            }
+        }
+    };
+    auto load_planes = [&](uint4 (&sx)[PRE][4], int v0w, int first) {       // planes first .. min(first + PRE, P) - 1 -> sx[0..]
+#pragma unroll
+        for (int p = 0; p < PRE; ++p) {
+            const int pl = first + p;
+            if (pl >= P) break;
+            const bf16_t* src = pl < NP ? a.vpos + pl * a.vts : a.vneg + (pl - NP) * a.vts;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = l + 64 * q, row = i >> 3, c = i & 7;
+                sx[p][q] = *reinterpret_cast<const uint4*>(src + (int64_t)min(v0w + row, a.V - 1) * a.Bp + 8 * c);
+            }
+        }
+    };
+    auto write_plane = [&](char* dst, const uint4 (&x)[4], bool negate) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = l + 64 * q, row = i >> 3, c = i & 7;
+            uint4 v = x[q];
+            if (negate) { v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u; }
+            *reinterpret_cast<uint4*>(dst + row * K3_ROWB + 16 * c) = v;
+        }
+    };
+
+    float4 wA[16], mA[16], wB[16], mB[16];
+    load_tile(wA, mA, tile0 * 128, true);                               // weight stream starts first
+    k3_stage<true, HT>(sHp, a.hpos, a.hts, h0, a.H, a.Bp, 0, false);    // hidden planes: once per block
+    k3_stage<true, HT>(sHn, a.hneg, a.hts, h0, a.H, a.Bp, 0, false);
+    __syncthreads();                                                    // the ONLY block barrier: from here the waves run independently
+
+    auto tile = [&](int it, float4 (&wc)[16], float4 (&mc)[16], float4 (&wn)[16], float4 (&mn)[16]) {
+        const int v0 = (tile0 + it) * 128;
+        uint4 sx[PRE][4];
+        load_planes(sx, v0 + 32 * w, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(wn, mn, v0 + 128, it + 1 < n_my);                      // next tile's weights: in flight for the whole tile
+        __builtin_amdgcn_sched_barrier(0);
+        write_plane(s0, sx[0], 0 >= NP);
+        if constexpr (P > 1) write_plane(s1, sx[1], 1 >= NP);
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {                                    // positive terms then (negated) negative terms
+            if constexpr (P > PRE) if (p == PRE - 2) load_planes(sx, v0 + 32 * w, PRE);   // 3+3 terms: last two planes reuse sx[0..1] (they queue behind the prefetch)
+            __builtin_amdgcn_wave_barrier();
+            k3_mfma_wave<HT>(acc, p < NP ? sHp : sHn, (p & 1) ? s1 : s0, r, kh);
+            if (p + 2 < P) {
+                __builtin_amdgcn_wave_barrier();
+                write_plane((p & 1) ? s1 : s0, sx[(p + 2) % PRE], p + 2 >= NP);   // LDS ops of a wave are in order
+            }
+        }
+        auto epilogue = [&](auto pow2_tag) {
+            constexpr bool POW2 = decltype(pow2_tag)::value;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = v0 + 32 * w + mfma_row(reg, l);
+                if (row < a.V && cok) {
+                    const float4 d = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);   // pos_assoc - neg_assoc
+                    if constexpr (MODE == 0) {
+                        const int64_t idx = (int64_t)row * a.ldw + h0 + 4 * r;
+                        const float4 w0 = wc[reg];
+                        float4 m = mc[reg];
+                        const float gx = POW2 ? d.x * inv_n : d.x / a.n, gy = POW2 ? d.y * inv_n : d.y / a.n;
+                        const float gz = POW2 ? d.z * inv_n : d.z / a.n, gw = POW2 ? d.w * inv_n : d.w / a.n;
+                        m.x = m.x * a.mom; m.x = m.x + a.lr * (gx - a.wd * w0.x);        // rbm.py:212
+                        m.y = m.y * a.mom; m.y = m.y + a.lr * (gy - a.wd * w0.y);
+                        m.z = m.z * a.mom; m.z = m.z + a.lr * (gz - a.wd * w0.z);
+                        m.w = m.w * a.mom; m.w = m.w + a.lr * (gw - a.wd * w0.w);
+                        *reinterpret_cast<float4*>(a.Wm + idx) = m;
+                        *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
+                    } else {
+                        *reinterpret_cast<float4*>(a.delta + (int64_t)row * a.H + h0 + 4 * r) = d;
+                    }
+                }
+            }
+        };
+        if (n_pow2) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    };
+    for (int it = 0; it < n_my; it += 2) {
+        tile(it, wA, mA, wB, mB);
+        if (it + 1 < n_my) tile(it + 1, wB, mB, wA, mA);
+    }
+}
+
 template <int MODE, int HT>
 __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block,
                                                               const BiasArgs bias, int bias_rows) {
@@ -723,7 +847,6 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
                   reinterpret_cast<double*>(smem));
         return;
     }
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, kh = l >> 5;
     // XCD-aware block -> (hidden tile bx, visible chunk by) map.  Blocks are dealt round-robin to the 8 XCDs
     // (private L2 each), so give XCD x the sub-grid (xa of the hidden tiles) x (xc of the visible chunks),
     // xa*xc = 8: the operand planes a block stages were then already fetched into THIS L2 by a neighbour
@@ -742,82 +865,19 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
             by = (xcd / xa) * sc + slot / sa;
         }
     }
-    const int h0 = bx * 128;
     const int tile0 = by * tiles_per_block;
-    const int n_vtiles = (a.V + 127) / 128;
-    const int n_my = min(tiles_per_block, n_vtiles - tile0);
     const int ncbv = ((a.V + 15) / 16 * 16 + 63) / 64;
     const int nap = operand_terms(a.vpos_flag, ncbv, a.Bp / 8, (tile0 * 128) / 64, (tile0 + tiles_per_block) * 2, a.vpos_terms);
     const int nan_ = a.vneg_terms;
-    const int colc = min(h0 + 4 * r, a.H - 4);
-    const bool cok = (h0 + 4 * r) < a.H;          // H % 4 == 0: a float4 is entirely inside or outside
-
-    char* sHp = smem;
-    char* sHn = smem + 3 * K3_PLANE;
-    char* sVw = smem + 6 * K3_PLANE + w * (2 * 32 * K3_ROWB);     // this wave's two 32-row visible slices
-
-    auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0) {
-        if constexpr (MODE == 0) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t idx = (int64_t)min(v0 + 32 * w + mfma_row(reg, l), a.V - 1) * a.ldw + colc;
-                wo[reg] = *reinterpret_cast<const float4*>(a.W + idx);
-                mo[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
-            }
-        }
-    };
-
-    float4 wA[16], mA[16], wB[16], mB[16];
-    load_tile(wA, mA, tile0 * 128);                                     // weight stream starts first
-    k3_stage<true, HT>(sHp, a.hpos, a.hts, h0, a.H, a.Bp, 0, false);    // hidden planes: once per block
-    k3_stage<true, HT>(sHn, a.hneg, a.hts, h0, a.H, a.Bp, 0, false);
-    __syncthreads();                                                    // the ONLY block barrier: from here the waves run independently
-
-    int vbuf = 0;
-    auto tile = [&](int it, float4 (&wc)[16], float4 (&mc)[16], float4 (&wn)[16], float4 (&mn)[16]) {
-        const int v0 = (tile0 + it) * 128;
-        f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        // positive then negative phase, one visible plane (term) at a time, staged by this wave for itself
-        for (int ph = 0; ph < 2; ++ph) {
-            const int nt_ = ph ? nan_ : nap;
-            for (int ta = 0; ta < nt_; ++ta) {
-                char* sVc = sVw + vbuf * (32 * K3_ROWB);
-                k3_stage_wave(sVc, (ph ? a.vneg : a.vpos) + ta * a.vts, v0 + 32 * w, a.V, a.Bp, ph != 0);
-                __builtin_amdgcn_wave_barrier();
-                if (ph == 0 && ta == 0 && it + 1 < n_my) load_tile(wn, mn, v0 + 128);     // next tile's weights
-                k3_mfma_wave<HT>(acc, ph ? sHn : sHp, sVc, r, kh);
-                vbuf ^= 1;
-            }
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = v0 + 32 * w + mfma_row(reg, l);
-            if (row < a.V && cok) {
-                const float4 d = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);   // pos_assoc - neg_assoc
-                if constexpr (MODE == 0) {
-                    const int64_t idx = (int64_t)row * a.ldw + h0 + 4 * r;
-                    const float4 w0 = wc[reg];
-                    float4 m = mc[reg];
-                    m.x = m.x * a.mom; m.x = m.x + a.lr * (d.x / a.n - a.wd * w0.x);        // rbm.py:212
-                    m.y = m.y * a.mom; m.y = m.y + a.lr * (d.y / a.n - a.wd * w0.y);
-                    m.z = m.z * a.mom; m.z = m.z + a.lr * (d.z / a.n - a.wd * w0.z);
-                    m.w = m.w * a.mom; m.w = m.w + a.lr * (d.w / a.n - a.wd * w0.w);
-                    *reinterpret_cast<float4*>(a.Wm + idx) = m;
-                    *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
-                } else {
-                    *reinterpret_cast<float4*>(a.delta + (int64_t)row * a.H + h0 + 4 * r) = d;
-                }
-            }
-        }
-    };
-    for (int it = 0; it < n_my; it += 2) {
-        tile(it, wA, mA, wB, mB);
-        if (it + 1 < n_my) tile(it + 1, wB, mB, wA, mA);
-    }
+    // block-uniform dispatch on the operand term counts (1 = exactly-bf16 values such as samples, 3 = fp32 split)
+#ifdef K3_ONLY
+    k3_body<MODE, HT, K3_ONLY / 10, K3_ONLY % 10>(a, smem, bx, by, tiles_per_block);
+#else
+    if (nap == 1 && nan_ == 1)      k3_body<MODE, HT, 1, 1>(a, smem, bx, by, tiles_per_block);
+    else if (nap == 1 && nan_ == 3) k3_body<MODE, HT, 1, 3>(a, smem, bx, by, tiles_per_block);
+    else if (nap == 3 && nan_ == 1) k3_body<MODE, HT, 3, 1>(a, smem, bx, by, tiles_per_block);
+    else                            k3_body<MODE, HT, 3, 3>(a, smem, bx, by, tiles_per_block);
+#endif
 }
 
 }  // namespace imdbn

@@ -606,9 +606,12 @@ __global__ __launch_bounds__(256) void assoc_update(const AssocArgs a) {
 //     VALU bound at one wave per SIMD (75 us).
 // grid = (ceil(H/128), ceil(V/128)), block = 256 (wave w: rows v0+32w..+31), 144 KB dynamic LDS.
 // ------------------------------------------------------------------------------------------
-constexpr int K3_ROWB = 144;                 // padded LDS row: 64 bf16 = 128 B + 16 B
-constexpr int K3_PLANE = 128 * K3_ROWB;      // one plane of 128 features
-constexpr int K3_LDS_BYTES = 8 * K3_PLANE;   // 6 hidden planes (pos/neg x 3 terms) + 2 visible planes (or time-shared)
+constexpr int K3_ROWB = 128;                 // LDS row: 64 bf16 (one batch chunk), unpadded; 16-B chunk c of row r sits at
+                                             // position c ^ ((r >> 1) & 7): 16 consecutive rows x one chunk = 64 distinct banks
+constexpr int K3_PLANE = 128 * K3_ROWB;      // one plane of 128 hidden features (16 KB)
+constexpr int K3_SLICE = 32 * K3_ROWB;       // one wave's 32 visible rows of one plane (4 KB)
+constexpr int K3_VIS0 = 6 * K3_PLANE;        // 6 hidden planes (pos / neg x 3 terms), then 4 waves x 4 slices
+constexpr int K3_LDS_BYTES = K3_VIS0 + 4 * 4 * K3_SLICE;      // 160 KB: the whole LDS of a CU
 
 struct AssocPlanesArgs {
     float* W; float* Wm; int64_t ldw; int V, H;
@@ -621,12 +624,14 @@ struct AssocPlanesArgs {
     float* delta;
 };
 
-// copy `nplanes` planes of 128 features x 64 batch rows (chunk b0) into LDS; PERM: hidden-side row permutation.
-// Per plane a thread moves 4 of the 1024 16-B chunks; the loads of a plane pair are issued as one batch
-// (a load->store loop would serialise one L2 round trip per chunk).
-template <bool PERM, int NPL>
+__device__ __forceinline__ int k3_swz(int row, int c) { return row * K3_ROWB + ((c ^ ((row >> 1) & 7)) << 4); }
+
+// copy NPL hidden planes of 128 features x 64 batch rows into LDS (whole block, once).  Feature 4r+t goes to
+// row t*32+r so that lane r of an MFMA B fragment owns output columns 4r..4r+3 (float4 weight accesses).
+// Per plane a thread moves 4 of the 1024 16-B chunks; all loads are issued before the first LDS write.
+template <int NPL>
 __device__ __forceinline__ void k3_stage(char* dst, const bf16_t* src, int64_t term_stride, int f0, int F,
-                                         int Bp, int b0, bool negate) {
+                                         int Bp, bool negate) {
     const int tid = threadIdx.x;
     uint4 x[NPL][4];
 #pragma unroll
@@ -634,7 +639,7 @@ __device__ __forceinline__ void k3_stage(char* dst, const bf16_t* src, int64_t t
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = tid + 256 * q, row = i >> 3, c = i & 7;
-            x[pl][q] = *reinterpret_cast<const uint4*>(src + pl * term_stride + (int64_t)min(f0 + row, F - 1) * Bp + b0 + 8 * c);
+            x[pl][q] = *reinterpret_cast<const uint4*>(src + pl * term_stride + (int64_t)min(f0 + row, F - 1) * Bp + 8 * c);
         }
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
@@ -643,85 +648,56 @@ __device__ __forceinline__ void k3_stage(char* dst, const bf16_t* src, int64_t t
             const int i = tid + 256 * q, row = i >> 3, c = i & 7;
             uint4 v = x[pl][q];
             if (negate) { v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u; }
-            const int lrow = PERM ? ((row & 3) * 32 + (row >> 2)) : row;
-            *reinterpret_cast<uint4*>(dst + pl * K3_PLANE + lrow * K3_ROWB + 16 * c) = v;
+            const int lrow = (row & 3) * 32 + (row >> 2);
+            *reinterpret_cast<uint4*>(dst + pl * K3_PLANE + k3_swz(lrow, c)) = v;
         }
     __builtin_amdgcn_sched_barrier(0);     // keep the batches apart: at most NPL*4 staging registers live at once
 }
 
-template <int HT, int NA>
-__device__ __forceinline__ void k3_mfma(f32x16 (&acc)[4], const char* sH, const char* sV, int w, int r, int kh) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        uint4 af[NA];
-#pragma unroll
-        for (int ta = 0; ta < NA; ++ta)
-            af[ta] = *reinterpret_cast<const uint4*>(sV + ta * K3_PLANE + (32 * w + r) * K3_ROWB + 32 * kb + 16 * kh);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int tb = 0; tb < HT; ++tb) {
-                const uint4 bf = *reinterpret_cast<const uint4*>(sH + tb * K3_PLANE + (t * 32 + r) * K3_ROWB + 32 * kb + 16 * kh);
-#pragma unroll
-                for (int ta = 0; ta < NA; ++ta)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af[ta]), as_frag(bf), acc[t], 0, 0, 0);
-            }
-    }
+// gfx950 direct global -> LDS load: lane i's 16 bytes land at LDS[lds_off + 16*i] (checked on hardware:
+// tools/ldsdma_test.hip).  No destination registers, no ds_write.  Written as asm because the builtin form is a
+// FLAT op: the compiler then flushes vmcnt AND lgkmcnt to 0 at the next dependent wait, which would drain the
+// weight prefetch.  The compiler does not count these ops; every wait it computes is then at worst too strict
+// (vmcnt retires in order), never too weak, and the "slices arrived" wait below is explicit.
+__device__ __forceinline__ void k3_dma16(const void* g, uint32_t lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "s"(lds_off) : "memory", "m0");
 }
 
-// Streaming form: block (bx, by) owns hidden columns [128*bx, +128) and the `tiles_per_block` visible
-// tiles starting at tile by*tiles_per_block.  The hidden planes (pos+neg, HT terms: up to 108 KB) are
-// staged ONCE and stay in LDS; per visible tile only one 18-KB visible plane per term is re-staged
-// (two buffers alternate -> one barrier per plane), and the float4 W / W_m tile of the NEXT visible
-// tile is prefetched into a second register set while the current tile runs its MFMAs + epilogue
-// (one wave per SIMD, 512 registers).  Operand re-reads drop from ~120 MB to ~50 MB per launch and
-// the weight stream never waits on a dependent load.
-// Requires Bp == 64 (one batch chunk) and 16-B aligned weight rows; otherwise the generic kernel runs.
-// Wave-private staging of this wave's 32 visible rows of one plane (64 batch rows): 256 16-B chunks,
-// 4 per lane, loads first.  No block barrier: only this wave reads the slice (LDS ops of a wave are in order).
-__device__ __forceinline__ void k3_stage_wave(char* dst, const bf16_t* src, int v0w, int V, int Bp, bool negate) {
-    const int l = threadIdx.x & 63;
-    uint4 x[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = l + 64 * q, row = i >> 3, c = i & 7;
-        x[q] = *reinterpret_cast<const uint4*>(src + (int64_t)min(v0w + row, V - 1) * Bp + 8 * c);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = l + 64 * q, row = i >> 3, c = i & 7;
-        uint4 v = x[q];
-        if (negate) { v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u; }
-        *reinterpret_cast<uint4*>(dst + row * K3_ROWB + 16 * c) = v;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// MFMAs of one visible plane (single term, wave-private slice sVw) against HT hidden planes
+// MFMAs of one visible plane slice (single term, this wave's 32 rows) against HT hidden planes
 template <int HT>
 __device__ __forceinline__ void k3_mfma_wave(f32x16 (&acc)[4], const char* sH, const char* sVw, int r, int kh) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        const uint4 af = *reinterpret_cast<const uint4*>(sVw + r * K3_ROWB + 32 * kb + 16 * kh);
+        const int off = k3_swz(r, 2 * kb + kh);                  // (t*32 + r) >> 1 & 7 == r >> 1 & 7: same swizzle for every t
+        const uint4 af = *reinterpret_cast<const uint4*>(sVw + off);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int tb = 0; tb < HT; ++tb) {
-                const uint4 bf = *reinterpret_cast<const uint4*>(sH + tb * K3_PLANE + (t * 32 + r) * K3_ROWB + 32 * kb + 16 * kh);
+                const uint4 bf = *reinterpret_cast<const uint4*>(sH + tb * K3_PLANE + t * 32 * K3_ROWB + off);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af), as_frag(bf), acc[t], 0, 0, 0);
             }
     }
 }
 
-// One block's stream of visible tiles for a fixed (NP, NN) = number of bf16 terms of the positive / negative
-// visible operand.  Per tile and wave the VMEM order is: [all NP+NN plane slices of this wave -> registers]
-// [next tile's W, W_m -> registers] ... [this tile's stores].  vmcnt retires in order, so a plane wait
-// placed after the weight prefetch would drain the prefetch; with this order the only waits are
-// "planes arrived" (weights stay in flight for the whole tile) and, implicitly, the previous tile's stores.
-// No conditional sits between a load and its wait (a divergent count makes the compiler wait for 0).
-template <int MODE, int HT, int NP, int NN>
-__device__ __attribute__((noinline)) void k3_body(const AssocPlanesArgs& a, char* smem, int bx, int by, int tiles_per_block) {
-    constexpr int P = NP + NN, PRE = P < 4 ? P : 4;     // planes staged in registers ahead of the weight prefetch
+// Streaming form: block (bx, by) owns hidden columns [128*bx, +128) and the `tiles_per_block` visible tiles
+// starting at tile by*tiles_per_block; wave w owns rows 32w..32w+31 of every tile.  The hidden planes (pos and
+// NEGATED neg, HT terms: 96 KB) are staged once and stay in LDS.  nap / nan = number of bf16 terms (1 or 3) of the
+// positive / negative visible operand (block-uniform run-time values), P = nap + nan planes per tile.
+// Per tile and wave the VMEM order is
+//   [DMA the first min(P,4) plane slices -> LDS] [next tile's W, W_m -> registers] ... [this tile's stores]
+// vmcnt retires in order, so a wait for the slices leaves exactly the 32 prefetch loads in flight for the whole
+// tile (MFMAs + epilogue); a plane load placed after the prefetch would drain it (only the 3+3-term case has
+// such late planes).  No conditional sits between the loads and the wait: the prefetch of a non-existent next
+// tile collapses onto one row, unused slices are still loaded (clamped plane index, L2 hits).
+// After the hidden staging there is no block barrier: the four waves run independently and drift apart, which
+// smooths the load / store bursts.  One wave per SIMD (two 128-register weight tiles in flight).
+// Requires Bp == 64 (one batch chunk) and 16-B aligned weight rows; otherwise the generic kernel runs.
+template <int MODE, int HT>
+__device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, int bx, int by, int tiles_per_block,
+                                        int nap, int nan_) {
+    const int P = nap + nan_;                                       // 2, 4 or 6 planes per tile
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, kh = l >> 5;
     const int h0 = bx * 128;
     const int tile0 = by * tiles_per_block;
@@ -734,11 +710,9 @@ __device__ __attribute__((noinline)) void k3_body(const AssocPlanesArgs& a, char
 
     char* sHp = smem;
     char* sHn = smem + 3 * K3_PLANE;
-    char* s0 = smem + 6 * K3_PLANE + w * (2 * 32 * K3_ROWB);     // this wave's two 32-row visible slices
-    char* s1 = s0 + 32 * K3_ROWB;
+    char* sV = smem + K3_VIS0 + w * (4 * K3_SLICE);                    // this wave's four slices
+    const uint32_t sV_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sV);
 
-    // `valid` false (no next tile): every row index collapses to the tile's first row -> the 16 loads hit the
-    // same two lines (no traffic), but the load COUNT stays fixed
     auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0, bool valid) {
         if constexpr (MODE == 0) {
 #pragma unroll
@@ -750,59 +724,53 @@ __device__ __attribute__((noinline)) void k3_body(const AssocPlanesArgs& a, char
             }
         }
     };
-    auto load_planes = [&](uint4 (&sx)[PRE][4], int v0w, int first) {       // planes first .. min(first + PRE, P) - 1 -> sx[0..]
-#pragma unroll
-        for (int p = 0; p < PRE; ++p) {
-            const int pl = first + p;
-            if (pl >= P) break;
-            const bf16_t* src = pl < NP ? a.vpos + pl * a.vts : a.vneg + (pl - NP) * a.vts;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = l + 64 * q, row = i >> 3, c = i & 7;
-                sx[p][q] = *reinterpret_cast<const uint4*>(src + (int64_t)min(v0w + row, a.V - 1) * a.Bp + 8 * c);
-            }
-        }
-    };
-    auto write_plane = [&](char* dst, const uint4 (&x)[4], bool negate) {
+    // plane pl (positive terms first, then negative terms) of rows v0w..v0w+31 -> slice `slot`
+    auto dma_plane = [&](int slot, int pl, int v0w) {
+        pl = min(pl, P - 1);
+        const bf16_t* src = pl < nap ? a.vpos + pl * a.vts : a.vneg + (pl - nap) * a.vts;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = l + 64 * q, row = i >> 3, c = i & 7;
-            uint4 v = x[q];
-            if (negate) { v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u; }
-            *reinterpret_cast<uint4*>(dst + row * K3_ROWB + 16 * c) = v;
+            const int i = l + 64 * q, row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);      // source chunk for LDS position i
+            k3_dma16(src + (int64_t)min(v0w + row, a.V - 1) * a.Bp + 8 * c, sV_lds + slot * K3_SLICE + q * 1024);
         }
     };
 
     float4 wA[16], mA[16], wB[16], mB[16];
     load_tile(wA, mA, tile0 * 128, true);                               // weight stream starts first
-    k3_stage<true, HT>(sHp, a.hpos, a.hts, h0, a.H, a.Bp, 0, false);    // hidden planes: once per block
-    k3_stage<true, HT>(sHn, a.hneg, a.hts, h0, a.H, a.Bp, 0, false);
-    __syncthreads();                                                    // the ONLY block barrier: from here the waves run independently
+    k3_stage<HT>(sHp, a.hpos, a.hts, h0, a.H, a.Bp, false);             // hidden planes: once per block
+    k3_stage<HT>(sHn, a.hneg, a.hts, h0, a.H, a.Bp, true);              // negative phase enters the accumulator negated
+    __syncthreads();                                                    // the ONLY block barrier
 
     auto tile = [&](int it, float4 (&wc)[16], float4 (&mc)[16], float4 (&wn)[16], float4 (&mn)[16]) {
         const int v0 = (tile0 + it) * 128;
-        uint4 sx[PRE][4];
-        load_planes(sx, v0 + 32 * w, 0);
+        // the previous tile's MFMAs have consumed their fragments (ds_reads retire before the MFMA issues)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dma_plane(p, p, v0 + 32 * w);
         __builtin_amdgcn_sched_barrier(0);
         load_tile(wn, mn, v0 + 128, it + 1 < n_my);                      // next tile's weights: in flight for the whole tile
         __builtin_amdgcn_sched_barrier(0);
-        write_plane(s0, sx[0], 0 >= NP);
-        if constexpr (P > 1) write_plane(s1, sx[1], 1 >= NP);
+        if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");     // slices arrived; prefetch still in flight
+        else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {                                    // positive terms then (negated) negative terms
-            if constexpr (P > PRE) if (p == PRE - 2) load_planes(sx, v0 + 32 * w, PRE);   // 3+3 terms: last two planes reuse sx[0..1] (they queue behind the prefetch)
-            __builtin_amdgcn_wave_barrier();
-            k3_mfma_wave<HT>(acc, p < NP ? sHp : sHn, (p & 1) ? s1 : s0, r, kh);
-            if (p + 2 < P) {
-                __builtin_amdgcn_wave_barrier();
-                write_plane((p & 1) ? s1 : s0, sx[(p + 2) % PRE], p + 2 >= NP);   // LDS ops of a wave are in order
+        for (int p = 0; p < 6; ++p) {
+            if (p < P) {                                                  // block-uniform
+                if (p >= 4) {                                             // 3+3 terms only: planes 4, 5 reuse slices 0, 1
+                    if (p == 4) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // fragments of planes 0, 1 are in registers
+                        dma_plane(0, 4, v0 + 32 * w);
+                        dma_plane(1, 5, v0 + 32 * w);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+                k3_mfma_wave<HT>(acc, p < nap ? sHp : sHn, sV + (p & 3) * K3_SLICE, r, kh);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // all fragment reads done before the next tile's DMA overwrites the slices
         auto epilogue = [&](auto pow2_tag) {
             constexpr bool POW2 = decltype(pow2_tag)::value;
 #pragma unroll
@@ -839,7 +807,7 @@ __device__ __attribute__((noinline)) void k3_body(const AssocPlanesArgs& a, char
 template <int MODE, int HT>
 __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block,
                                                               const BiasArgs bias, int bias_rows) {
-    __shared__ __attribute__((aligned(16))) char smem[K3_LDS_BYTES];      // 144 KB static (the CU has 160 KB)
+    __shared__ __attribute__((aligned(16))) char smem[K3_LDS_BYTES];      // 160 KB static: all of the CU's LDS
     // The last `bias_rows` block rows of the grid do the (tiny, independent) bias / loss update of
     // rbm.py:216-226 instead of a dependent launch of their own: they only touch the bias vectors.
     if (bias_rows > 0 && (int)blockIdx.y >= (int)gridDim.y - bias_rows) {
@@ -869,15 +837,7 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
     const int ncbv = ((a.V + 15) / 16 * 16 + 63) / 64;
     const int nap = operand_terms(a.vpos_flag, ncbv, a.Bp / 8, (tile0 * 128) / 64, (tile0 + tiles_per_block) * 2, a.vpos_terms);
     const int nan_ = a.vneg_terms;
-    // block-uniform dispatch on the operand term counts (1 = exactly-bf16 values such as samples, 3 = fp32 split)
-#ifdef K3_ONLY
-    k3_body<MODE, HT, K3_ONLY / 10, K3_ONLY % 10>(a, smem, bx, by, tiles_per_block);
-#else
-    if (nap == 1 && nan_ == 1)      k3_body<MODE, HT, 1, 1>(a, smem, bx, by, tiles_per_block);
-    else if (nap == 1 && nan_ == 3) k3_body<MODE, HT, 1, 3>(a, smem, bx, by, tiles_per_block);
-    else if (nap == 3 && nan_ == 1) k3_body<MODE, HT, 3, 1>(a, smem, bx, by, tiles_per_block);
-    else                            k3_body<MODE, HT, 3, 3>(a, smem, bx, by, tiles_per_block);
-#endif
+    k3_body<MODE, HT>(a, smem, bx, by, tiles_per_block, nap, nan_);
 }
 
 }  // namespace imdbn

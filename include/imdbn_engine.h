@@ -125,6 +125,9 @@ int    imdbn_set_option(const char* name, int value);
 /* per-kernel timing of the update kernel with HIP events on the launch stream (bench.py roofline) */
 int    imdbn_profile_enable(int on);
 int    imdbn_profile_read(double* total_ms, int* launches);   /* synchronises the recorded events */
+/* tuning aid: copies the per-block wall-clock stamps (100 MHz ticks, 8 per block, up to 4096 blocks) that the
+ * propagation kernels record when the "dbg" option enables them; synchronises the device */
+int    imdbn_debug_stamps(long long* out, int n);
 
 /* ---- K1: p(h|v)   replaces RBM.forward (rbm.py:81-92) ---------------------------------- */
 /* out_prob[B][H] = sigmoid((v W + c)/T);  out_sample (nullable) = 1[out_prob > U] */

@@ -92,6 +92,12 @@ __device__ __forceinline__ int operand_terms(const int* map, int ncb, int P, int
     return __any(any) ? 3 : 1;
 }
 
+// Debug timeline (tools/stamps_probe.py): per-block wall-clock stamps (100 MHz), enabled by the `dbg` option bits.
+__device__ long long g_stamps[4096 * 8];
+__device__ __forceinline__ void stamp(bool on, int blk, int slot) {
+    if (on && threadIdx.x == 0 && blk < 4096) g_stamps[blk * 8 + slot] = wall_clock64();
+}
+
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace imdbn

@@ -25,6 +25,7 @@ int g_ks_up = 0, g_ks_down = 0;
 bool g_no_fast_k3 = false;
 bool g_no_fast_k1 = false;
 bool g_no_fused_up = false;
+int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
 int g_dbg = 0;    // tuning/testing: force the generic K3
 
 int fail(int code, const char* fmt, ...) {
@@ -88,8 +89,34 @@ struct Layout {
     float* f_v[2];
     float* cs_hpos; float* cs_hneg; float* cs_vpos; float* cs_vneg;
     float* loss_part; int n_loss_slots;
+    int down_tr;            // visible rows per block of the fused K2 (<= 32): balances the row tiles over the CUs
     size_t bytes;
 };
+
+int cu_count() {
+    static int cus = 0;
+    if (cus <= 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else return 256;
+    }
+    return cus;
+}
+
+// Fused K2 streams W once, one tile of `tr` visible rows per block, and every block costs the same; the kernel
+// ends when the CU with the most rows ends (blocks are dealt round-robin).  10000 rows as 313 tiles of 32 put two
+// tiles (64 rows) on 57 of the 256 CUs and one on the rest: the main loop ran 13 us at the median and 20 us on
+// those 57.  20-row tiles (500 blocks, two per CU, 40 rows each) level it.  The MFMA tile stays 32 wide.
+int plan_down_rows(int V) {
+    if (g_down_tr > 0) return g_down_tr;
+    const int cus = cu_count();
+    int best = 32, best_cost = 1 << 30;
+    for (int tr = 32; tr >= 16; tr -= 4) {
+        const int cost = cdiv(cdiv(V, tr), cus) * tr;       // rows streamed by the busiest CU
+        if (cost < best_cost) { best_cost = cost; best = tr; }
+    }
+    return best;
+}
 
 Layout make_layout(int V, int H, int B, char* base) {
     Layout L{};
@@ -107,6 +134,7 @@ Layout make_layout(int V, int H, int B, char* base) {
         L.up = plan_split(L.Vpad, cdiv(H, 64), mb, g_ks_up, 64);
     }
     L.down = plan_split(L.Hpad, cdiv(V, 64), mb, g_ks_down, 16);
+    L.down_tr = plan_down_rows(V);
     size_t off = 0;
     auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return p; };
     // exactness maps of caller-supplied operands (prep rewrites them every call): visible side, hidden side
@@ -125,7 +153,7 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.cs_hneg = (float*)take((size_t)L.P * H * 4);
     L.cs_vpos = (float*)take((size_t)L.P * V * 4);
     L.cs_vneg = (float*)take((size_t)L.P * V * 4);
-    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 32) * (L.Bp / 64)) + IMDBN_MAX_GROUPS * (L.Bp / 64);
+    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 16) * (L.Bp / 64)) + IMDBN_MAX_GROUPS * (L.Bp / 64);
     L.loss_part = (float*)take((size_t)L.n_loss_slots * 4);
     L.bytes = off;
     return L;
@@ -252,6 +280,8 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     const imdbn_rbm_desc* d = c.d;
     base_finish_args(c, up, f);
     if (f.T < 1e-6f) f.T = 1e-6f;                           // max(1e-6, T)  rbm.py:92,96
+    // lean epilogue specialisation (kernels_ew.hpp finish_rows_impl<R, false>)
+    f.simple = (f.T == 1.0f && !(f.sigma > 0.f) && !f.mu && !f.clamp && f.n_groups == 0 && !f.logits_only) ? 1 : 0;
     const int mb = L.Bp / 64;
     if (up && L.Vpad <= 1024 && !g_no_fused_up) {
         // short K: fused GEMM + epilogue, no split-K slabs (one launch per half step of a chain)
@@ -285,13 +315,13 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
         // K2: fused GEMM + epilogue (no split-K slabs)
         if (f.n_groups > 0 && !f.logits_only && !f.out_prob) f.out_prob = L.f_vp, f.ld_prob = L.V;
         if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
-        dim3 grid(cdiv(L.V, 32), 1, mb);
+        dim3 grid(cdiv(L.V, L.down_tr), 1, mb);
         f.dbg = g_dbg;
         const int64_t ats = (int64_t)L.Bp * L.Hpad;
         const bool vec4 = (d->ldw % 4 == 0) && (((uintptr_t)d->W & 15) == 0) && (L.H % 4 == 0) && L.H >= 4;
         if ((int)((grid.x + IMDBN_MAX_GROUPS) * grid.z) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
 #define LAUNCH_DOWN(NW, V4) \
-    hipLaunchKernelGGL((gemm_down_fused<NW, V4>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f)
+    hipLaunchKernelGGL((gemm_down_fused<NW, V4>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f, L.down_tr)
         if (c.nw == 3) { if (vec4) LAUNCH_DOWN(3, true); else LAUNCH_DOWN(3, false); }
         else           { if (vec4) LAUNCH_DOWN(1, true); else LAUNCH_DOWN(1, false); }
 #undef LAUNCH_DOWN
@@ -307,6 +337,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
     dim3 fgrid(cdiv(f.N, 64), L.P);
     if ((int)(fgrid.x * fgrid.y) + IMDBN_MAX_GROUPS * (L.Bp / 64) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
+    f.dbg = g_dbg;
     hipLaunchKernelGGL(finish, fgrid, dim3(256), 0, c.s, f);
     HIPCHK(hipGetLastError());
     if (f.n_groups > 0 && !f.logits_only) {
@@ -317,7 +348,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
 }
 int n_loss_used(const Ctx& c, bool up) {
     if (up) return cdiv(c.L.H, 64) * c.L.P;
-    return (cdiv(c.L.V, 32) + c.d->n_groups) * (c.L.Bp / 64);    // fused K2: one partial per block (+ per group block)
+    return (cdiv(c.L.V, c.L.down_tr) + c.d->n_groups) * (c.L.Bp / 64);    // fused K2: one partial per block (+ per group block)
 }
 
 // caller fp32 tensor -> operand forms in the workspace
@@ -362,7 +393,7 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
         f.vpos = a.vpos; f.vpos_flag = a.vpos_flag; f.vpos_terms = a.vpos_terms;
         f.hpos = a.hpos; f.vneg = a.vneg; f.vneg_terms = a.vneg_terms; f.hneg = a.hneg;
         f.vts = a.vts; f.hts = a.hts; f.Bp = a.Bp;
-        f.lr = a.lr; f.mom = a.mom; f.wd = a.wd; f.n = a.n; f.delta = a.delta;
+        f.lr = a.lr; f.mom = a.mom; f.wd = a.wd; f.n = a.n; f.delta = a.delta; f.dbg = (g_dbg & 512) ? 1 : 0;
         // ~one block per CU: each block streams `tpb` visible tiles with its hidden planes resident in LDS
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -552,6 +583,7 @@ int imdbn_set_option(const char* name, int value) {
     if (!strcmp(name, "ksplit_up")) g_ks_up = std::max(0, value);
     else if (!strcmp(name, "ksplit_down")) g_ks_down = std::max(0, value);
     else if (!strcmp(name, "generic_k3")) g_no_fast_k3 = value != 0;
+    else if (!strcmp(name, "down_rows")) { if (value != 0 && (value < 4 || value > 32 || value % 4)) return fail(IMDBN_E_INVALID, "down_rows must be 0 or a multiple of 4 in [4, 32]"); g_down_tr = value; }
     else if (!strcmp(name, "dbg")) g_dbg = value;
     else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
     else if (!strcmp(name, "no_fused_up")) g_no_fused_up = value != 0;
@@ -567,6 +599,15 @@ int imdbn_profile_enable(int on) {
     g_prof.on = on != 0;
     g_prof.used = 0;
     g_prof.calls = 0;
+    return 0;
+}
+
+int imdbn_debug_stamps(long long* out, int n) {
+    if (!out || n <= 0 || n > 4096 * 8) return fail(IMDBN_E_INVALID, "imdbn_debug_stamps: bad buffer");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * (size_t)n, 0, hipMemcpyDeviceToHost));
+    static const std::vector<long long> zeros(4096 * 8, 0);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros.data(), sizeof(long long) * zeros.size(), 0, hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -23,34 +23,96 @@ struct OperandOut {
     // so the MFMA A-fragment load of a wave (32 rows x 2 halves x 16 B) is ONE contiguous KB.
     bf16_t* rm; int64_t rm_ts; int ldrm; int rm_terms; int Bp;
     bf16_t* tr; int64_t tr_ts; int tr_terms;             // transposed  [t][N][Bp]
+    int tr_negate;                                       // store the transposed planes with the sign flipped
 };
 
-__device__ __forceinline__ uint32_t piece(float x, int t, int terms) {
-    if (terms == 1) return bf16_rne(x);
-    uint32_t p[3];
-    split3(x, p[0], p[1], p[2]);
-    return t == 0 ? p[0] : (t == 1 ? p[1] : p[2]);
+// bf16 terms of R values: terms == 1 -> one round-to-nearest bf16 (exact for samples / exactly-bf16 data),
+// terms == 3 -> hi/mid/lo truncation split (fp32-exact products).  Computed ONCE per element and shared by
+// the two operand forms.
+template <int R>
+__device__ __forceinline__ void pieces(const float (&x)[R], int terms, uint32_t (&pc)[3][R]) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (terms == 1) { pc[0][i] = bf16_rne(x[i]); pc[1][i] = 0u; pc[2][i] = 0u; }
+        else split3(x[i], pc[0][i], pc[1][i], pc[2][i]);
+    }
 }
 
-// x[i] = value at (row b0+i, col); rows >= B and cols >= N must already be 0.
-__device__ __forceinline__ void store_rm(const OperandOut& o, const float (&x)[8], int b0, int col) {
+// pc[t][i] = term t of the value at (row b0+i, col); rows >= B and cols >= N must already be 0.
+template <int R>
+__device__ __forceinline__ void store_rm_pc(const OperandOut& o, const uint32_t (&pc)[3][R], int b0, int col) {
     if (o.rm && col < o.ldrm) {
-        for (int t = 0; t < o.rm_terms; ++t)
+        bf16_t* q = o.rm + ((int64_t)(col >> 4) * o.Bp + b0) * 16 + (col & 15);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                o.rm[t * o.rm_ts + ((int64_t)(col >> 4) * o.Bp + (b0 + i)) * 16 + (col & 15)] = (bf16_t)piece(x[i], t, o.rm_terms);
+        for (int t = 0; t < 3; ++t)
+            if (t < o.rm_terms) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) q[t * o.rm_ts + i * 16] = (bf16_t)pc[t][i];
+            }
     }
 }
-__device__ __forceinline__ void store_tr(const OperandOut& o, const float (&x)[8], int b0, int col, int N, int Bp) {
+template <int R>
+__device__ __forceinline__ void store_tr_pc(const OperandOut& o, const uint32_t (&pc)[3][R], int b0, int col, int N, int Bp) {
+    static_assert(R == 8 || R == 2, "rows per thread");
     if (o.tr && col < N) {
-        for (int t = 0; t < o.tr_terms; ++t) {
-            uint32_t p[8];
+        bf16_t* q = o.tr + (int64_t)col * Bp + b0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) p[i] = piece(x[i], t, o.tr_terms);
-            *reinterpret_cast<uint4*>(o.tr + t * o.tr_ts + (int64_t)col * Bp + b0) =
-                make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
-        }
+        for (int t = 0; t < 3; ++t)
+            if (t < o.tr_terms) {
+                const uint32_t sg = o.tr_negate ? 0x80008000u : 0u;      // negative-phase planes are stored negated for K3
+                if constexpr (R == 8)
+                    *reinterpret_cast<uint4*>(q + t * o.tr_ts) =
+                        make_uint4((pc[t][0] | (pc[t][1] << 16)) ^ sg, (pc[t][2] | (pc[t][3] << 16)) ^ sg,
+                                   (pc[t][4] | (pc[t][5] << 16)) ^ sg, (pc[t][6] | (pc[t][7] << 16)) ^ sg);
+                else
+                    *reinterpret_cast<uint32_t*>(q + t * o.tr_ts) = (pc[t][0] | (pc[t][1] << 16)) ^ sg;
+            }
     }
+}
+// LDS staging of a block's K16-blocked operand tile: buf[t][kb][row][16] for the block's `nkb` 16-column groups
+// x `rows` batch rows.  2-byte scattered global stores are processed about a lane at a time (24 of them per
+// thread were ~5 us of the fused K2 epilogue); through LDS the tile leaves as coalesced 16-B stores.
+struct RmStage { bf16_t* buf; int nkb, rows; int col0, row0; };
+
+template <int R>
+__device__ __forceinline__ void stage_rm_pc(const OperandOut& o, const RmStage& g, const uint32_t (&pc)[3][R], int b0, int col) {
+    const int lc = col - g.col0, lr = b0 - g.row0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < o.rm_terms) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) g.buf[(((t * g.nkb) + (lc >> 4)) * g.rows + lr + i) * 16 + (lc & 15)] = (bf16_t)pc[t][i];
+        }
+}
+// after a __syncthreads(): the whole block writes the staged tile (16 B per thread and step)
+__device__ __forceinline__ void flush_rm_stage(const OperandOut& o, const RmStage& g) {
+    if (!o.rm) return;
+    const int per_t = g.nkb * g.rows * 2, n = o.rm_terms * per_t;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int t = i / per_t, j = i - t * per_t;
+        const int half = j & 1, lr = (j >> 1) % g.rows, kb = (j >> 1) / g.rows;
+        const int gkb = (g.col0 >> 4) + kb;
+        if (gkb * 16 < o.ldrm)
+            *reinterpret_cast<uint4*>(o.rm + t * o.rm_ts + ((int64_t)gkb * o.Bp + g.row0 + lr) * 16 + 8 * half) =
+                *reinterpret_cast<const uint4*>(g.buf + ((t * g.nkb + kb) * g.rows + lr) * 16 + 8 * half);
+    }
+}
+
+// both operand forms of one source vector (the common case shares the split); stg != nullptr: the K16-blocked
+// form goes to the block's LDS stage (the caller flushes it), otherwise straight to memory
+template <int R>
+__device__ __forceinline__ void store_forms(const OperandOut& o, const float (&x)[R], bool rm, bool tr, int b0, int col, int N, int Bp,
+                                            const RmStage* stg = nullptr) {
+    uint32_t pc[3][R];
+    rm = rm && o.rm && col < o.ldrm;
+    if (rm && tr && o.rm_terms == o.tr_terms) {
+        pieces<R>(x, o.rm_terms, pc);
+        if (stg) stage_rm_pc<R>(o, *stg, pc, b0, col); else store_rm_pc<R>(o, pc, b0, col);
+        store_tr_pc<R>(o, pc, b0, col, N, Bp);
+        return;
+    }
+    if (rm) { pieces<R>(x, o.rm_terms, pc); if (stg) stage_rm_pc<R>(o, *stg, pc, b0, col); else store_rm_pc<R>(o, pc, b0, col); }
+    if (tr) { pieces<R>(x, o.tr_terms, pc); store_tr_pc<R>(o, pc, b0, col, N, Bp); }
 }
 
 struct FinishArgs {
@@ -69,6 +131,7 @@ struct FinishArgs {
     OperandOut op; int rm_src, tr_src;             // 0 none, 1 prob, 2 final
     float* colsum_part; int colsum_src;            // [Bp/32][N]
     const float* loss_ref; int64_t ld_ref; int loss_src; float* loss_part;   // one per block (+ one per group)
+    int simple;                                    // set by the host: none of T / noise / mu / clamp / groups / logits_only in use
     int dbg;                                       // timing experiments only: 1 = skip epilogue, 2 = skip GEMM loop
 };
 
@@ -85,70 +148,126 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Epilogue of one column x 8 consecutive batch rows, given the pre-bias sums xs[8].
-// part_row = index of this 8-row group in the column-sum partials.  Returns the squared-error partial.
-__device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int b0, const float (&xs)[8], int part_row) {
-    const bool cok = col < a.N;
-    const bool grp = cok && in_group(a, col);
+// Epilogue of one column x R consecutive batch rows (R = 8, or 2 when a block spreads an 8-row group over its
+// four waves), given the pre-bias sums xs[R].  Returns the squared-error partial; csum = this thread's share of
+// the column sum (the caller stores / combines it).
+// Side inputs of the epilogue of one column x R rows.  All are loaded up front, UNCONDITIONALLY, from clamped
+// addresses (rows >= B and columns >= N are discarded later): a load inside the per-row branches would cost one
+// dependent memory round trip per row.  A fused GEMM kernel issues them BEFORE its main loop.
+template <int R>
+struct SideIn { float bias; float ref[R], mk[R], kn[R], mu[R]; };
+
+template <int R>
+__device__ __forceinline__ void load_side(const FinishArgs& a, int col, int b0, SideIn<R>& s) {
     const int cc = min(col, a.N - 1);
-    const float bias = a.bias[cc];
-    // All side inputs are loaded up front, UNCONDITIONALLY, from clamped addresses (rows >= B and
-    // columns >= N are discarded below): a load inside the per-row branches would cost one dependent
-    // memory round trip per row.
-    float ref[8], mk[8], kn[8], mu[8];
+    s.bias = a.bias[cc];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < R; ++i) {
         const int bc = min(b0 + i, a.B - 1);
-        ref[i] = a.loss_ref ? a.loss_ref[(int64_t)bc * a.ld_ref + cc] : 0.f;
-        mk[i] = a.clamp ? a.mask[(int64_t)bc * a.ldk + cc] : 0.f;
-        kn[i] = a.clamp ? a.vk[(int64_t)bc * a.ldk + cc] : 0.f;
-        mu[i] = (a.mu && cc < a.Dz) ? a.mu[(int64_t)bc * a.ldmu + cc] : 0.f;
+        s.ref[i] = a.loss_ref ? a.loss_ref[(int64_t)bc * a.ld_ref + cc] : 0.f;
+        s.mk[i] = a.clamp ? a.mask[(int64_t)bc * a.ldk + cc] : 0.f;
+        s.kn[i] = a.clamp ? a.vk[(int64_t)bc * a.ldk + cc] : 0.f;
+        s.mu[i] = (a.mu && cc < a.Dz) ? a.mu[(int64_t)bc * a.ldmu + cc] : 0.f;
     }
-    const bool pull = a.mu && col < a.Dz;
-    float xp[8], xf[8];
-    float csum = 0.f, lsum = 0.f;
+}
+
+// EX = false is the lean specialisation for the plain case (a.simple: T == 1, no noise, no mu-pull, no clamp, no
+// softmax groups, not logits-only): the full version keeps so many FinishArgs fields live that the compiler
+// re-fetches kernel arguments and walks a chain of scalar branches for every row (5 of the 7 us of the fused K2
+// epilogue).  Sampling (vmode) stays a run-time switch in both.
+template <int R, bool EX>
+__device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, int b0, const float (&xs)[R], const SideIn<R>& sd, float& csum,
+                                                  const RmStage* stg) {
+    const bool cok = col < a.N;
+    const bool grp = EX && cok && in_group(a, col);
+    const int cc = min(col, a.N - 1);
+    const float bias = sd.bias;
+    const bool pull = EX && a.mu && col < a.Dz;
+    const bool clamp = EX && a.clamp;
+    const bool raw = EX && (a.logits_only || grp);      // group columns: logits now, softmax etc. in finish_groups
+    const int vmode = a.vmode, colsum_src = a.colsum_src, loss_src = a.loss_src;
+    const bool has_ref = a.loss_ref != nullptr;
+    float* const out_prob = a.out_prob; float* const out_final = a.out_final;
+    float xp[R], xf[R];
+    float lsum = 0.f;
+    csum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < R; ++i) {
         const int b = b0 + i;
         const bool live = cok && b < a.B;
         const int bd = min(b, a.B - 1);             // draws for padded rows / columns: clamped, result discarded
         float x = xs[i] + bias;
-        if (a.T != 1.0f) x = x / a.T;
-        if (a.sigma > 0.f) x = x + draw_normal(a.noise, bd, cc) * a.sigma;
+        if constexpr (EX) {
+            if (a.T != 1.0f) x = x / a.T;
+            if (a.sigma > 0.f) x = x + draw_normal(a.noise, bd, cc) * a.sigma;
+        }
         float p = sigmoidf_ref(x);
-        if (pull) p = (1.0f - a.eta) * p + a.eta * mu[i];
-        const float mixed = a.clamp ? (p * (1.0f - mk[i]) + kn[i] * mk[i]) : p;
+        if (pull) p = (1.0f - a.eta) * p + a.eta * sd.mu[i];
+        const float mixed = clamp ? (p * (1.0f - sd.mk[i]) + sd.kn[i] * sd.mk[i]) : p;
         float v;
-        if (a.vmode == 0) {
+        if (vmode == 0) {
             v = mixed;
         } else {
             const float u = draw_uniform(a.uni, bd, cc);
-            if (a.vmode == 1) {
+            if (vmode == 1) {
                 const float smp = (p > u) ? 1.f : 0.f;
-                v = a.clamp ? (smp * (1.0f - mk[i]) + kn[i] * mk[i]) : smp;
+                v = clamp ? (smp * (1.0f - sd.mk[i]) + sd.kn[i] * sd.mk[i]) : smp;
             } else {
                 v = (mixed > u) ? 1.f : 0.f;
             }
         }
-        const bool raw = a.logits_only || grp;      // group columns: logits now, softmax etc. in finish_groups
         if (live) {
-            if (a.out_prob) a.out_prob[(int64_t)b * a.ld_prob + col] = raw ? x : p;
-            if (a.out_final && !raw) a.out_final[(int64_t)b * a.ld_final + col] = v;
+            if (out_prob) out_prob[(int64_t)b * a.ld_prob + col] = raw ? x : p;
+            if (out_final && !raw) out_final[(int64_t)b * a.ld_final + col] = v;
         }
         const bool use = live && !raw;
         xp[i] = use ? p : 0.f;
         xf[i] = use ? v : 0.f;
         if (use) {
-            csum += (a.colsum_src == 2 ? v : p);
-            const float dlt = ref[i] - (a.loss_src == 2 ? v : p);
-            lsum += a.loss_ref ? dlt * dlt : 0.f;
+            csum += (colsum_src == 2 ? v : p);
+            const float dlt = sd.ref[i] - (loss_src == 2 ? v : p);
+            lsum += has_ref ? dlt * dlt : 0.f;
         }
     }
-    if (!a.logits_only && !grp) {   // group columns get their operand forms from finish_groups
-        if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
-        if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
+    if (!raw) {   // group columns get their operand forms from finish_groups
+        if (a.rm_src == a.tr_src) {
+            if (a.rm_src) store_forms<R>(a.op, a.rm_src == 2 ? xf : xp, true, true, b0, col, a.N, a.Bp, stg);
+        } else {
+            if (a.rm_src) store_forms<R>(a.op, a.rm_src == 2 ? xf : xp, true, false, b0, col, a.N, a.Bp, stg);
+            if (a.tr_src) store_forms<R>(a.op, a.tr_src == 2 ? xf : xp, false, true, b0, col, a.N, a.Bp);
+        }
     }
-    if (a.colsum_part && cok) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
+    // (softmax-group columns of a staged tile are flushed with whatever the stage holds and then rewritten by
+    //  finish_groups, which runs after this kernel)
+    return lsum;
+}
+
+template <int R>
+__device__ __forceinline__ float finish_rows(const FinishArgs& a, int col, int b0, const float (&xs)[R], const SideIn<R>& sd, float& csum,
+                                             const RmStage* stg = nullptr) {
+    if (a.simple) return finish_rows_impl<R, false>(a, col, b0, xs, sd, csum, stg);
+    return finish_rows_impl<R, true>(a, col, b0, xs, sd, csum, stg);
+}
+
+template <int R>
+__device__ __forceinline__ float finish_rows(const FinishArgs& a, int col, int b0, const float (&xs)[R], float& csum) {
+    SideIn<R> sd;
+    load_side<R>(a, col, b0, sd);
+    return finish_rows<R>(a, col, b0, xs, sd, csum);
+}
+
+// one column x 8 rows per thread: part_row = index of this 8-row group in the column-sum partials
+__device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int b0, const float (&xs)[8], int part_row, const SideIn<8>& sd,
+                                              const RmStage* stg = nullptr) {
+    float csum;
+    const float lsum = finish_rows<8>(a, col, b0, xs, sd, csum, stg);
+    if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
+    return lsum;
+}
+__device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int b0, const float (&xs)[8], int part_row) {
+    float csum;
+    const float lsum = finish_rows<8>(a, col, b0, xs, csum);
+    if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
     return lsum;
 }
 
@@ -156,11 +275,15 @@ __device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int 
 // column for 8 rows (all loads of a quarter in flight together), the quarters are combined through LDS in
 // a fixed order, and wave 0 runs the per-element epilogue.  grid = (ceil(N/64), Bp/8).
 __global__ __launch_bounds__(256) void finish(const FinishArgs a) {
-    __shared__ float part[3][8][64];
+    __shared__ float part[4][8][64];
+    __shared__ __attribute__((aligned(16))) bf16_t rmst[3 * 4 * 8 * 16];      // K16-blocked operand tile: [term][4 column groups][8 rows][16]
     const int c = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
     const int b0 = blockIdx.y * 8;
     float xs[8];
+    const bool st = (a.dbg & 256) != 0;
+    const int sblk = blockIdx.y * gridDim.x + blockIdx.x;
+    stamp(st, sblk, 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) xs[i] = 0.f;
     if (col < a.N) {
@@ -183,19 +306,37 @@ __global__ __launch_bounds__(256) void finish(const FinishArgs a) {
             }
         }
     }
-    if (kq > 0) {
+    // every wave contributes its slab quarter of all 8 rows, then takes TWO rows of the epilogue (the per-element
+    // work -- Philox draws, sigmoid, bf16 splits -- on one wave alone was the critical path of this kernel)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) part[kq - 1][i][c] = xs[i];
+    for (int i = 0; i < 8; ++i) part[kq][i][c] = xs[i];
+    stamp(st, sblk, 1);
+    __syncthreads();
+    stamp(st, sblk, 2);
+    float x2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = 2 * kq + i;
+        x2[i] = ((part[0][rr][c] + part[1][rr][c]) + part[2][rr][c]) + part[3][rr][c];
     }
+    float csum;
+    SideIn<2> sd;
+    load_side<2>(a, col, b0 + 2 * kq, sd);
+    const bool staged = a.rm_src && !a.logits_only;
+    const RmStage stg{rmst, 4, 8, (int)blockIdx.x * 64, b0};
+    const float lsum = finish_rows<2>(a, col, b0 + 2 * kq, x2, sd, csum, staged ? &stg : nullptr);
+    stamp(st, sblk, 3);
+    __syncthreads();                                   // part[] is consumed: reuse it for the column / loss sums
+    if (staged) flush_rm_stage(a.op, stg);
+    part[kq][0][c] = csum;
+    const float t = wave_sum(lsum);
+    if (c == 0) part[kq][1][0] = t;
     __syncthreads();
     if (kq == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xs[i] = ((xs[i] + part[0][i][c]) + part[1][i][c]) + part[2][i][c];
-        const float lsum = finish_rows8(a, col, b0, xs, blockIdx.y);
-        if (a.loss_part) {
-            const float t = wave_sum(lsum);
-            if (c == 0) a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
-        }
+        if (a.colsum_part && col < a.N)
+            a.colsum_part[(int64_t)blockIdx.y * a.N + col] = ((part[0][0][c] + part[1][0][c]) + part[2][0][c]) + part[3][0][c];
+        if (a.loss_part && c == 0)
+            a.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = ((part[0][1][0] + part[1][1][0]) + part[2][1][0]) + part[3][1][0];
     }
 }
 
@@ -283,8 +424,12 @@ __global__ __launch_bounds__(256) void finish_groups(const FinishArgs a, int los
             xp[i] = ok ? p : 0.f;
             xf[i] = ok ? v : 0.f;
         }
-        if (a.rm_src) store_rm(a.op, a.rm_src == 2 ? xf : xp, b0, col);
-        if (a.tr_src) store_tr(a.op, a.tr_src == 2 ? xf : xp, b0, col, a.N, a.Bp);
+        if (a.rm_src == a.tr_src) {
+            if (a.rm_src) store_forms<8>(a.op, a.rm_src == 2 ? xf : xp, true, true, b0, col, a.N, a.Bp);
+        } else {
+            if (a.rm_src) store_forms<8>(a.op, a.rm_src == 2 ? xf : xp, true, false, b0, col, a.N, a.Bp);
+            if (a.tr_src) store_forms<8>(a.op, a.tr_src == 2 ? xf : xp, false, true, b0, col, a.N, a.Bp);
+        }
         if (a.colsum_part) a.colsum_part[(int64_t)(b0 >> 3) * a.N + col] = csum;
     }
     if (a.loss_part) {
@@ -334,8 +479,7 @@ __global__ __launch_bounds__(64) void prep_operand(const PrepArgs a) {
     // plain store, rewritten by every call: no zeroing / atomics; consumers OR the entries they cover
     if (a.flag) { const bool any = __any(inexact ? 1 : 0) != 0; if (c == 0) a.flag[blockIdx.y * gridDim.x + blockIdx.x] = any ? 1 : 0; }
     if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = csum;
-    store_rm(a.op, x, b0, col);
-    store_tr(a.op, x, b0, col, a.N, a.Bp);
+    store_forms<8>(a.op, x, true, true, b0, col, a.N, a.Bp);
 }
 
 // rbm.py:216-226.  parts are [P][len] column-sum partials; loss parts are summed in double.

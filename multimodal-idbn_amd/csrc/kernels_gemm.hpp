@@ -250,6 +250,9 @@ __device__ __forceinline__ void up4_body(const float* __restrict__ W, int64_t ld
     };
     UpOperands<NA> ring[D];
     const int kb0 = k_begin + 16 * w;
+    const int sblk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const bool st = (dbg & 4) != 0;
+    stamp(st, sblk, 1);
 #pragma unroll
     for (int d = 0; d < D; ++d) load(ring[d], kb0 + 64 * d);
     for (int kb = kb0; kb < k_end; kb += 64 * D) {
@@ -259,9 +262,11 @@ __device__ __forceinline__ void up4_body(const float* __restrict__ W, int64_t ld
             if (kb + 64 * d < k_end && !(dbg & 1)) compute(ring[d]);      // wave-uniform
             else if (dbg & 1) acc[0][0][0] += ring[d].wv[0].x + __uint_as_float(ring[d].av[0][0].x);
             __builtin_amdgcn_sched_barrier(0);
+            if (kb == kb0 && d == 0) stamp(st, sblk, 2);
             load(ring[d], kb + 64 * (d + D));                             // refill D blocks ahead
         }
     }
+    stamp(st, sblk, 3);
     // cross-wave reduction (fixed order) and float4 slab stores: thread -> 4 interleaved columns of one row
     float* slab = partial + (int64_t)ks * Bp * N;
     const bool cok = (n0 + 4 * r) < N;
@@ -286,6 +291,7 @@ __device__ __forceinline__ void up4_body(const float* __restrict__ W, int64_t ld
             if (cok) *reinterpret_cast<float4*>(slab + (int64_t)row * N + n0 + 4 * r) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+    stamp(st, sblk, 4);
 }
 
 template <int NW>
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(256, 1) void gemm_up4_partial(
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
     float* __restrict__ partial, int Bp, int kchunk, int dbg) {
     __shared__ float red[4 * 4 * 16 * 64];      // 64 KB
+    stamp((dbg & 4) != 0, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 0);
     const int na = operand_terms(a_flag, (lda + 63) / 64, Bp / 8, (blockIdx.y * kchunk) / 64, (blockIdx.y * kchunk + kchunk + 63) / 64, a_terms);
     if (na == 1) up4_body<NW, 1>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red, dbg);
     else         up4_body<NW, 3>(W, ldw, K, N, A, a_term_stride, lda, partial, Bp, kchunk, red, dbg);
@@ -319,17 +326,20 @@ struct DownOperands {
 template <bool UP, int NW, bool VEC4, int NA>
 __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int64_t ldw, int K, int N,
                                                 const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
-                                                const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33]) {
+                                                const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33], int TR) {
     constexpr int D = 4;                     // operand ring depth: D x (2 KB weights + activations) in flight per wave
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
-    const int n0 = blockIdx.x * 32, mb = blockIdx.z * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, hh = l >> 5;
+    // the block owns output columns [n0, n0 + TR), TR <= 32 (host: plan_down_rows); MFMA lanes >= TR repeat the last
+    // column (same addresses -> no extra traffic) and their results are dropped
+    const int r = l & 31, rc = min(r, TR - 1);
+    const int n0 = blockIdx.x * TR, mb = blockIdx.z * 64;
     f32x16 acc[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
     // UP: W is [K][N] (the tile's column, 8 K rows = 8 dword loads); DOWN: W is [N][K] (8 contiguous floats)
-    const float* wrow = UP ? (W + min(n0 + r, N - 1)) : (W + (int64_t)min(n0 + r, N - 1) * ldw);
+    const float* wrow = UP ? (W + min(n0 + rc, N - 1)) : (W + (int64_t)min(n0 + rc, N - 1) * ldw);
     const int64_t arow0 = mb + r, arow1 = mb + 32 + r;
     auto load = [&](DownOperands<NA>& o, int kb) {
         const int kbc = min(kb, lda - 16);              // clamped: blocks past the end are loaded but never used
@@ -349,6 +359,7 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
         }
 #pragma unroll
         for (int ta = 0; ta < NA; ++ta) {
+            if (fa.dbg & 8) { o.av[ta][0] = make_uint4(kb, 0, 0, 0); o.av[ta][1] = make_uint4(0, kb, 0, 0); continue; }
             o.av[ta][0] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow0) * 16 + 8 * hh);
             o.av[ta][1] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow1) * 16 + 8 * hh);
         }
@@ -369,19 +380,29 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     // (whole 128-B lines per wave instead of lines split between waves).  Register ring, static slots.
     DownOperands<NA> ring[D];
     const int nblk = lda / 16;
+    const int sblk = blockIdx.z * gridDim.x + blockIdx.x;
+    const bool st = (fa.dbg & 128) != 0;
+    stamp(st, sblk, 1);
+    // epilogue side inputs (bias, loss reference, clamp / mu planes) of this thread's column x 8 rows: issued now,
+    // consumed after the K loop (their first-touch latency used to sit on every block's critical path)
+    SideIn<8> side;
+    load_side<8>(fa, (tid & 31) < TR ? n0 + (tid & 31) : (1 << 30), mb + (tid >> 5) * 8, side);
 #pragma unroll
     for (int d = 0; d < D; ++d) load(ring[d], 16 * (w * D + d));
     for (int g = 0; (4 * g + w) * D < ((fa.dbg & 2) ? 0 : nblk); ++g) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             __builtin_amdgcn_sched_barrier(0);
-            if ((4 * g + w) * D + d < nblk) compute(ring[d]);             // wave-uniform
+            if (fa.dbg & 4) acc[0][0] += ring[d].wv[0] + ring[d].wv[7] + __uint_as_float(ring[d].av[0][0].x) + __uint_as_float(ring[d].av[0][1].w);
+            else if ((4 * g + w) * D + d < nblk) compute(ring[d]);             // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
             load(ring[d], 16 * ((4 * (g + 1) + w) * D + d));              // refill the slot for the next group
         }
     }
     // cross-wave reduction (fixed order) into tile[batch row][column]
+    stamp(st, sblk, 2);
     __syncthreads();
+    stamp(st, sblk, 3);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -397,12 +418,23 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     __syncthreads();
     // epilogue: 256 threads = 32 columns x 8 row-octets
     const int c = tid & 31, oct = tid >> 5;
+    const int ecol = c < TR ? n0 + c : (1 << 30);          // columns past the tile: nothing stored
     float xs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) xs[i] = tile[oct * 8 + i][c];
     float lsum = 0.f;
-    if (!(fa.dbg & 1)) lsum = finish_rows8(fa, n0 + c, mb + oct * 8, xs, (mb >> 3) + oct);
+    stamp(st, sblk, 4);
+    // the reduction buffer is free again: it stages the K16-blocked operand tile [term][2 column groups][64 rows][16]
+    const bool staged = fa.rm_src && !fa.logits_only && TR == 32;      // needs 16-column-aligned tiles
+    const RmStage stg{reinterpret_cast<bf16_t*>(red), 2, 64, n0, mb};
+    if (!(fa.dbg & 1)) lsum = finish_rows8(fa, ecol, mb + oct * 8, xs, (mb >> 3) + oct, side, staged ? &stg : nullptr);
     else if (xs[0] == 123.456f) fa.out_prob[0] = xs[1];
+    stamp(st, sblk, 5);
+    if (staged) {
+        __syncthreads();
+        flush_rm_stage(fa.op, stg);
+    }
+    stamp(st, sblk, 6);
     if (fa.loss_part) {
         __syncthreads();
         const float t = wave_sum(lsum);
@@ -416,12 +448,13 @@ template <int NW, bool VEC4>
 __global__ __launch_bounds__(256, 2) void gemm_down_fused(
     const float* __restrict__ W, int64_t ldw, int K, int N,
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
-    const FinishArgs fa) {
+    const FinishArgs fa, int tile_rows) {
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
+    stamp((fa.dbg & 128) != 0, blockIdx.z * gridDim.x + blockIdx.x, 0);
     const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
-    if (na == 1) down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
-    else         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
+    if (na == 1) down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+    else         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
 }
 
 // K1 fused with its epilogue for SHORT visible dimensions (K = V <= 1024: joint RBM, chains): same
@@ -434,8 +467,8 @@ __global__ __launch_bounds__(256, 2) void gemm_up_fused(
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
     const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
-    if (na == 1) down_fused_body<true, NW, false, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
-    else         down_fused_body<true, NW, false, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile);
+    if (na == 1) down_fused_body<true, NW, false, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, 32);
+    else         down_fused_body<true, NW, false, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, 32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -453,6 +486,7 @@ struct AssocArgs {
     int64_t vts, hts; int Bp;
     float lr, mom, wd, n;
     float* delta;
+    int dbg;
 };
 
 // All operand fragments of one 16-row batch block for this wave's 32(v) x 64(h) tile.
@@ -622,6 +656,7 @@ struct AssocPlanesArgs {
     int64_t vts, hts; int Bp;
     float lr, mom, wd, n;
     float* delta;
+    int dbg;
 };
 
 __device__ __forceinline__ int k3_swz(int row, int c) { return row * K3_ROWB + ((c ^ ((row >> 1) & 7)) << 4); }
@@ -736,10 +771,14 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
     };
 
     float4 wA[16], mA[16], wB[16], mB[16];
+    const bool st = a.dbg != 0;
+    const int sblk = by * gridDim.x + bx;
+    stamp(st, sblk, 0);
     load_tile(wA, mA, tile0 * 128, true);                               // weight stream starts first
     k3_stage<HT>(sHp, a.hpos, a.hts, h0, a.H, a.Bp, false);             // hidden planes: once per block
     k3_stage<HT>(sHn, a.hneg, a.hts, h0, a.H, a.Bp, true);              // negative phase enters the accumulator negated
     __syncthreads();                                                    // the ONLY block barrier
+    stamp(st, sblk, 1);
 
     auto tile = [&](int it, float4 (&wc)[16], float4 (&mc)[16], float4 (&wn)[16], float4 (&mn)[16]) {
         const int v0 = (tile0 + it) * 128;
@@ -797,6 +836,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
             }
         };
         if (n_pow2) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        stamp(st, sblk, 2 + it);
     };
     for (int it = 0; it < n_my; it += 2) {
         tile(it, wA, mA, wB, mB);

@@ -8,6 +8,7 @@ timeout -k 10 500 python -m pytest tests -m gpu -q -x --timeout=300 > gpurun_out
 rc=$?; echo "pytest exit $rc" | tee -a gpurun_out/pytest_gpu.log
 if [ $rc -ge 124 ]; then tail -40 gpurun_out/pytest_gpu.log; echo "pytest was killed: no further GPU step in this call"; exit $rc; fi
 tail -40 gpurun_out/pytest_gpu.log
+if [ $rc -ne 0 ]; then echo "PYTEST FAILED: skipping bench"; exit $rc; fi
 timeout -k 10 120 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -3 gpurun_out/smoke.log
 timeout -k 10 200 python bench.py --steps 200 --warmup 20 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -2 gpurun_out/bench.log
 # kernel trace of the same bench command (summary copied to profiles/ by hand)

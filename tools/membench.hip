@@ -184,5 +184,31 @@ int main() {
         printf("sequence 3x read(W): %.1f us/iter ; + rw4(W,Wm): %.1f us (marginal %.1f us) ; + rwlin: %.1f us (marginal %.1f us)\n",
                t0, t1, t1 - t0, t2, t2 - t0);
     }
+    // ---- step-shaped sequence: up4(W) down4(W) up4(W) rw4(W,Wm) per iteration, then leave one kernel out to get
+    // each pattern's MARGINAL cost when its input was last touched by a DIFFERENT pattern (no lucky L2 hits).
+    {
+        const int kchu = ((V + 21 - 1) / 21 + 63) / 64 * 64; const int ksu = (V + kchu - 1) / kchu;      // K1: ~21 K slices
+        auto L_up = [&] { hipLaunchKernelGGL((up<4, 1>), dim3((H + 127) / 128, ksu), dim3(256), 0, 0, Wb[0], kchu, sink); };
+        auto L_dn = [&](int ksd) { const int kch = ((H + ksd - 1) / ksd + 63) / 64 * 64; const int ks = (H + kch - 1) / kch;
+                                   hipLaunchKernelGGL((down4<1>), dim3((V + 63) / 64, ks), dim3(256), 0, 0, Wb[0], kch, sink); };
+        auto L_lin = [&] { hipLaunchKernelGGL(lin4, dim3(2048), dim3(256), 0, 0, (const float4*)Wb[0], n / 4, sink); };
+        auto L_rw = [&] { hipLaunchKernelGGL(rw4, dim3((H + 127) / 128, (V + 127) / 128), dim3(256), 0, 0, Wb[0], Mb[0]); };
+        auto timeit = [&](auto&& body) {
+            for (int i = 0; i < 3; ++i) body();
+            CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+            for (int i = 0; i < REP; ++i) body();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return 1e3 * ms / REP;
+        };
+        const double full = timeit([&] { L_up(); L_dn(1); L_up(); L_rw(); });
+        const double no_dn = timeit([&] { L_up(); L_up(); L_rw(); });
+        const double no_up = timeit([&] { L_up(); L_dn(1); L_rw(); });
+        const double dn2 = timeit([&] { L_up(); L_dn(2); L_up(); L_rw(); });
+        const double dn4 = timeit([&] { L_up(); L_dn(4); L_up(); L_rw(); });
+        const double lin = timeit([&] { L_up(); L_lin(); L_up(); L_rw(); });
+        const double no_rw = timeit([&] { L_up(); L_dn(1); L_up(); });
+        printf("step sequence up4,down4,up4,rw4: %.1f us/iter; marginal: down4(ks1) %.1f  down4(ks2) %.1f  down4(ks4) %.1f  lin4-in-place-of-down4 %.1f  up4 %.1f  rw4 %.1f\n",
+               full, full - no_dn, dn2 - no_dn, dn4 - no_dn, lin - no_dn, full - no_up, full - no_rw);
+    }
     return 0;
 }

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Per-block timelines of K1 / K2 (debug stamps): where does a 16 us kernel spend its time?"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "multimodal-idbn_amd")]
+import torch
+import __graft_entry__ as ge
+ge.build()
+from imdbn import engine as E
+from imdbn.engine import native
+from imdbn.models import RBM
+
+V, H, B = 10000, 1500, 64
+dev = torch.device("cuda")
+eng = E.get_hip_engine()
+rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
+x = (torch.rand(B, V) > 0.9).float().to(dev)
+E.set_rng(E.PhiloxRng(seed=2))
+for which, bit, nslots in (("K1 up4 (last launch = negative phase)", 64, 5), ("K2 down_fused", 128, 8),
+                           ("K2 down_fused, no operand stores", 128 + 1024, 7), ("K2 down_fused, no sigmoid", 128 + 2048, 7),
+                           ("K2 down_fused, neither", 128 + 1024 + 2048, 7),
+                           ("finish (last launch = hidden, negative phase)", 256, 4), ("K3 assoc_update_planes", 512, 6)):
+    eng.set_option("dbg", bit)
+    for i in range(20):
+        rbm.train_epoch(x, 0, 1, CD=1)
+    torch.cuda.synchronize()
+    buf = (C.c_longlong * (4096 * 8))()
+    native.check(native.lib().imdbn_debug_stamps(buf, 4096 * 8), "imdbn_debug_stamps")
+    a = np.frombuffer(buf, dtype=np.int64).reshape(4096, 8).copy()
+    nb = int((a[:, 0] > 0).sum())
+    a = a[:nb, :nslots].astype(np.float64) / 100.0     # us
+    t0 = a[:, 0].min()
+    a -= t0
+    print(f"== {which}: {nb} blocks; columns = stamp slots (us since first block start)")
+    for q, nm in ((0, "min"), (50, "p50"), (90, "p90"), (100, "max")):
+        print(f"   {nm:4s} " + " ".join(f"{np.percentile(a[:, j], q):7.2f}" for j in range(nslots)))
+    if nslots == 8:
+        print("   K2: slot7 (after per-row loop) - slot4 (epilogue start) p50: %.2f ; slot5 - slot7: %.2f" % (np.percentile(a[:, 7] - a[:, 4], 50), np.percentile(a[:, 5] - a[:, 7], 50)))
+        a = a[:, :7]; nslots = 7
+    d = np.diff(a, axis=1)
+    print("   phase durations p50: " + " ".join(f"{np.percentile(d[:, j], 50):7.2f}" for j in range(nslots - 1)))
+    print("   phase durations max: " + " ".join(f"{d[:, j].max():7.2f}" for j in range(nslots - 1)))
+eng.set_option("dbg", 0)

@@ -361,7 +361,7 @@ int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_
     p.op.tr = tr; p.op.tr_ts = (int64_t)N * c.L.Bp; p.op.tr_terms = 3;
     p.flag = flag;
     p.colsum_part = colsum;
-    hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(N, ldrm), 64), c.L.P), dim3(64), 0, c.s, p);
+    hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(N, ldrm), 64), c.L.P), dim3(256), 0, c.s, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -461,7 +461,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o) {
             FinishArgs f = new_finish();
             DrawSrc u = c.rng.floats(B, L.H);
             if (!last) { f.vmode = 1; f.uni = u; f.op.rm = L.hid_rm; f.op.rm_terms = 1; f.rm_src = 2; }
-            f.op.tr = L.hid_tr[1]; f.op.tr_terms = c.rt; f.tr_src = 1;
+            f.op.tr = L.hid_tr[1]; f.op.tr_terms = c.rt; f.tr_src = 1; f.op.tr_negate = 1;
             f.colsum_part = L.cs_hneg; f.colsum_src = 1;
             CHK(prop(c, true, OpIn{L.vis_rm[1], 1, nullptr}, f));
         }
@@ -506,7 +506,7 @@ int run_chain(Ctx& c, const float* vk, const float* mask, int64_t ldk, int init_
             p.op.tr = L.vis_tr[0]; p.op.tr_ts = (int64_t)L.V * L.Bp; p.op.tr_terms = c.rt;
             p.colsum_part = L.cs_vpos;
         }
-        hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Vpad, 64), L.P), dim3(64), 0, c.s, p);
+        hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Vpad, 64), L.P), dim3(256), 0, c.s, p);
         HIPCHK(hipGetLastError());
     }
     for (int t = 0; t < n_steps; ++t) {
@@ -815,7 +815,7 @@ int imdbn_rbm_clamped_step(const imdbn_rbm_desc* d, const float* v_known, const 
     }
     {   // H- = up(v_neg)  (rbm.py:471)
         FinishArgs f = new_finish();
-        f.op.tr = L.hid_tr[1]; f.op.tr_terms = c.rt; f.tr_src = 1;
+        f.op.tr = L.hid_tr[1]; f.op.tr_terms = c.rt; f.tr_src = 1; f.op.tr_negate = 1;
         f.colsum_part = L.cs_hneg; f.colsum_src = 1;
         CHK(prop(c, true, OpIn{L.vis_rm[1], o->sample_v ? 1 : c.rt, nullptr}, f));
     }

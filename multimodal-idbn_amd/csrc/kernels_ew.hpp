@@ -453,33 +453,49 @@ struct PrepArgs {
     float* colsum_part;            // [Bp/8][N] column sums over each 8-row group (sum data, rbm.py:223)
 };
 
-__global__ __launch_bounds__(64) void prep_operand(const PrepArgs a) {
-    const int c = threadIdx.x;
+// block = 64 columns x 8 rows, 256 threads = 64 columns x 4 row pairs: all loads unconditional (clamped) and
+// issued before any use; the K16-blocked form leaves through the LDS stage as 16-B stores.
+__global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
+    __shared__ float cs[4][64];
+    __shared__ int fl[4];
+    __shared__ __attribute__((aligned(16))) bf16_t rmst[3 * 4 * 8 * 16];
+    const int c = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
-    const int b0 = blockIdx.y * 8;
-    float x[8];
+    const int g0 = blockIdx.y * 8, b0 = g0 + 2 * kq;
+    const int cc = min(col, a.N - 1);
+    float v[2], m[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int bc = min(b0 + i, a.B - 1);
+        v[i] = a.in[(int64_t)bc * a.ld + cc];
+        m[i] = a.mix ? a.mask[(int64_t)bc * a.ldm + cc] : 1.0f;
+    }
+    float x[2];
     float csum = 0.f;
     bool inexact = false;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const int b = b0 + i;
-        x[i] = 0.f;
-        if (col < a.N && b < a.B) {
-            float v = a.in[(int64_t)b * a.ld + col];
-            if (a.mix) {
-                const float m = a.mask[(int64_t)b * a.ldm + col];
-                v = v * m + (1.0f - m) * draw_uniform(a.uni, b, col);
-            }
-            if (a.out_f32) a.out_f32[(int64_t)b * a.ldo + col] = v;
-            x[i] = v;
-            csum += v;
-            inexact |= (__float_as_uint(v) & 0xFFFFu) != 0u;
-        }
+        const bool live = col < a.N && b < a.B;
+        float t = v[i];
+        if (a.mix) t = t * m[i] + (1.0f - m[i]) * draw_uniform(a.uni, min(b, a.B - 1), cc);
+        if (live && a.out_f32) a.out_f32[(int64_t)b * a.ldo + col] = t;
+        x[i] = live ? t : 0.f;
+        csum += x[i];
+        inexact |= (__float_as_uint(x[i]) & 0xFFFFu) != 0u;
     }
-    // plain store, rewritten by every call: no zeroing / atomics; consumers OR the entries they cover
-    if (a.flag) { const bool any = __any(inexact ? 1 : 0) != 0; if (c == 0) a.flag[blockIdx.y * gridDim.x + blockIdx.x] = any ? 1 : 0; }
-    if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = csum;
-    store_forms<8>(a.op, x, true, true, b0, col, a.N, a.Bp);
+    const bool any = __any(inexact ? 1 : 0) != 0;
+    if (c == 0) fl[kq] = any ? 1 : 0;
+    cs[kq][c] = csum;
+    const RmStage stg{rmst, 4, 8, (int)blockIdx.x * 64, g0};
+    store_forms<2>(a.op, x, true, true, b0, col, a.N, a.Bp, &stg);
+    __syncthreads();
+    flush_rm_stage(a.op, stg);
+    if (kq == 0) {
+        // plain store, rewritten by every call: no zeroing / atomics; consumers OR the entries they cover
+        if (a.flag && c == 0) a.flag[blockIdx.y * gridDim.x + blockIdx.x] = (fl[0] | fl[1] | fl[2] | fl[3]);
+        if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = ((cs[0][c] + cs[1][c]) + cs[2][c]) + cs[3][c];
+    }
 }
 
 // rbm.py:216-226.  parts are [P][len] column-sum partials; loss parts are summed in double.

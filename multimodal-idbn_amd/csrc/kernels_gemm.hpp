@@ -510,10 +510,9 @@ __device__ __forceinline__ void assoc_load(AssocFrags<HT, NAP, NAN_>& f, const A
     for (int t = 0; t < NAP; ++t) f.ap[t] = *reinterpret_cast<const uint4*>(a.vpos + t * a.vts + vrow + kb);
 #pragma unroll
     for (int t = 0; t < NAN_; ++t) {
-        uint4 x = *reinterpret_cast<const uint4*>(a.vneg + t * a.vts + vrow + kb);
-        // negate the 8 bf16 values: acc accumulates X^T P+ - V'^T P- in one accumulator
-        x.x ^= 0x80008000u; x.y ^= 0x80008000u; x.z ^= 0x80008000u; x.w ^= 0x80008000u;
-        f.an[t] = x;
+        // the negative-phase HIDDEN planes are stored negated by their producer (OperandOut::tr_negate), so one
+        // accumulator collects X^T P+ - V'^T P- without touching the fragments
+        f.an[t] = *reinterpret_cast<const uint4*>(a.vneg + t * a.vts + vrow + kb);
     }
 }
 
@@ -696,7 +695,7 @@ __device__ __forceinline__ void k3_stage(char* dst, const bf16_t* src, int64_t t
 // (vmcnt retires in order), never too weak, and the "slices arrived" wait below is explicit.
 __device__ __forceinline__ void k3_dma16(const void* g, uint32_t lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(g), "s"(lds_off) : "memory", "m0");
+                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory", "m0");      // wave-uniform by construction
 }
 
 // MFMAs of one visible plane slice (single term, this wave's 32 rows) against HT hidden planes
@@ -774,9 +773,28 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
     const bool st = a.dbg != 0;
     const int sblk = by * gridDim.x + bx;
     stamp(st, sblk, 0);
-    load_tile(wA, mA, tile0 * 128, true);                               // weight stream starts first
-    k3_stage<HT>(sHp, a.hpos, a.hts, h0, a.H, a.Bp, false);             // hidden planes: once per block
-    k3_stage<HT>(sHn, a.hneg, a.hts, h0, a.H, a.Bp, true);              // negative phase enters the accumulator negated
+    // hidden planes, once per block: 2 x HT planes x 16 KB straight into LDS (gfx950 LDS-DMA, no staging registers),
+    // 16 wave-instructions per plane dealt to the four waves; THEN the first weight tile, so that "planes arrived"
+    // is a vmcnt(32) that leaves the weight loads in flight.  LDS chunk i' = 8*lrow + pos holds chunk
+    // pos ^ ((lrow >> 1) & 7) of feature row 4*(lrow & 31) + (lrow >> 5) (lane r of a B fragment owns columns 4r..4r+3).
+    // The negative-phase planes are stored negated by their producer (OperandOut::tr_negate).
+    const uint32_t sH_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int tb = 0; tb < HT; ++tb)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * w + jj, i = 64 * j + l, lrow = i >> 3, pos = i & 7;
+                const int row = 4 * (lrow & 31) + (lrow >> 5), c = pos ^ ((lrow >> 1) & 7);
+                const bf16_t* src = (ph ? a.hneg : a.hpos) + tb * a.hts + (int64_t)min(h0 + row, a.H - 1) * a.Bp + 8 * c;
+                k3_dma16(src, sH_lds + (3 * ph + tb) * K3_PLANE + j * 1024);
+            }
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(wA, mA, tile0 * 128, true);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                    // the ONLY block barrier
     stamp(st, sblk, 1);
 

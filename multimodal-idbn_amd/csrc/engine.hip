@@ -25,6 +25,7 @@ int g_ks_up = 0, g_ks_down = 0;
 bool g_no_fast_k3 = false;
 bool g_no_fast_k1 = false;
 bool g_no_fused_up = false;
+int g_no_bits = 0;  // testing: never use the bit-packed hidden operand
 int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
 int g_dbg = 0;    // tuning/testing: force the generic K3
 
@@ -83,6 +84,7 @@ struct Layout {
     bf16_t* vis_tr[2];
     bf16_t* hid_rm;
     bf16_t* hid_tr[2];
+    uint32_t* hid_bits; int ldbits;      // bit-packed sampled hidden states [Bp][ldbits]
     float* partial;
     float* f_h;
     float* f_vp;
@@ -144,6 +146,8 @@ Layout make_layout(int V, int H, int B, char* base) {
     for (int i = 0; i < 2; ++i) L.vis_tr[i] = (bf16_t*)take((size_t)3 * V * L.Bp * 2);
     L.hid_rm = (bf16_t*)take((size_t)3 * L.Bp * L.Hpad * 2);
     for (int i = 0; i < 2; ++i) L.hid_tr[i] = (bf16_t*)take((size_t)3 * H * L.Bp * 2);
+    L.ldbits = 2 * cdiv(L.Hpad, 64);
+    L.hid_bits = (uint32_t*)take((size_t)L.Bp * L.ldbits * 4);
     const size_t pf = std::max((size_t)L.up.ks * L.Bp * H, (size_t)L.down.ks * L.Bp * V);
     L.partial = (float*)take(pf * 4);
     L.f_h = (float*)take((size_t)L.Bp * H * 4);
@@ -211,6 +215,7 @@ struct Ctx {
     Rng rng;
     int nw;         // weight terms
     int rt;         // terms of a real-valued activation operand
+    bool hid_bits_ok = false;      // L.hid_bits describes the current contents of L.hid_rm
     Ctx(const imdbn_rbm_desc* d_, imdbn_rng* r, hipStream_t s_) : d(d_), s(s_), rng(r) {
         nw = d->mode == IMDBN_FAST_BF16 ? 1 : 3;
         rt = nw;
@@ -288,6 +293,8 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
         dim3 grid(cdiv(L.H, 32), 1, mb);
         const int64_t ats = (int64_t)L.Bp * L.Vpad;
         f.dbg = 0;
+        f.op.bits = nullptr;
+        if (f.op.rm == L.hid_rm) c.hid_bits_ok = false;
         if (c.nw == 3)
             hipLaunchKernelGGL(gemm_up_fused<3>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, f);
         else
@@ -317,13 +324,19 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
         if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
         dim3 grid(cdiv(L.V, L.down_tr), 1, mb);
         f.dbg = g_dbg;
+        // sampled hidden states left by `finish` in bit-packed form: 16x less activation traffic per block
+        const uint32_t* abits = (c.hid_bits_ok && in.rm == L.hid_rm && in.terms == 1 && !g_no_bits) ? L.hid_bits : nullptr;
         const int64_t ats = (int64_t)L.Bp * L.Hpad;
         const bool vec4 = (d->ldw % 4 == 0) && (((uintptr_t)d->W & 15) == 0) && (L.H % 4 == 0) && L.H >= 4;
         if ((int)((grid.x + IMDBN_MAX_GROUPS) * grid.z) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
-#define LAUNCH_DOWN(NW, V4) \
-    hipLaunchKernelGGL((gemm_down_fused<NW, V4>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f, L.down_tr)
-        if (c.nw == 3) { if (vec4) LAUNCH_DOWN(3, true); else LAUNCH_DOWN(3, false); }
-        else           { if (vec4) LAUNCH_DOWN(1, true); else LAUNCH_DOWN(1, false); }
+#define LAUNCH_DOWN(NW, V4, NAK, BITS) \
+    hipLaunchKernelGGL((gemm_down_fused<NW, V4, NAK, BITS>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f, L.down_tr, abits, L.ldbits)
+#define LAUNCH_DOWN_A(NW, V4) \
+    do { if (abits) LAUNCH_DOWN(NW, V4, 1, true); else if (in.terms == 1) LAUNCH_DOWN(NW, V4, 1, false); \
+         else if (in.terms == 3) LAUNCH_DOWN(NW, V4, 3, false); else LAUNCH_DOWN(NW, V4, 0, false); } while (0)
+        if (c.nw == 3) { if (vec4) LAUNCH_DOWN_A(3, true); else LAUNCH_DOWN_A(3, false); }
+        else           { if (vec4) LAUNCH_DOWN_A(1, true); else LAUNCH_DOWN_A(1, false); }
+#undef LAUNCH_DOWN_A
 #undef LAUNCH_DOWN
         HIPCHK(hipGetLastError());
         if (f.n_groups > 0 && !f.logits_only) {
@@ -338,6 +351,10 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
     dim3 fgrid(cdiv(f.N, 64), L.P);
     if ((int)(fgrid.x * fgrid.y) + IMDBN_MAX_GROUPS * (L.Bp / 64) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
     f.dbg = g_dbg;
+    // hidden samples (exactly 0/1, not mixed with clamped values) also leave in bit-packed form for the fused K2
+    const bool bits = up && f.op.rm == L.hid_rm && f.rm_src == 2 && f.vmode == 1 && !f.clamp && f.n_groups == 0 && !f.logits_only;
+    f.op.bits = bits ? L.hid_bits : nullptr; f.op.ldbits = L.ldbits;
+    if (up && f.op.rm == L.hid_rm) c.hid_bits_ok = bits;
     hipLaunchKernelGGL(finish, fgrid, dim3(256), 0, c.s, f);
     HIPCHK(hipGetLastError());
     if (f.n_groups > 0 && !f.logits_only) {
@@ -584,6 +601,7 @@ int imdbn_set_option(const char* name, int value) {
     else if (!strcmp(name, "ksplit_down")) g_ks_down = std::max(0, value);
     else if (!strcmp(name, "generic_k3")) g_no_fast_k3 = value != 0;
     else if (!strcmp(name, "down_rows")) { if (value != 0 && (value < 4 || value > 32 || value % 4)) return fail(IMDBN_E_INVALID, "down_rows must be 0 or a multiple of 4 in [4, 32]"); g_down_tr = value; }
+    else if (!strcmp(name, "no_bits")) g_no_bits = value;
     else if (!strcmp(name, "dbg")) g_dbg = value;
     else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
     else if (!strcmp(name, "no_fused_up")) g_no_fused_up = value != 0;

@@ -24,6 +24,9 @@ struct OperandOut {
     bf16_t* rm; int64_t rm_ts; int ldrm; int rm_terms; int Bp;
     bf16_t* tr; int64_t tr_ts; int tr_terms;             // transposed  [t][N][Bp]
     int tr_negate;                                       // store the transposed planes with the sign flipped
+    // bit-packed form of an exactly-{0,1} operand (sampled states): bits[(k >> 5)*Bp + b] bit (k & 31) (word-major: a wave's loads are contiguous); written
+    // only by `finish` (a wave = 64 consecutive columns), read by the fused K2 instead of the 16x larger bf16 form
+    uint32_t* bits; int ldbits;
 };
 
 // bf16 terms of R values: terms == 1 -> one round-to-nearest bf16 (exact for samples / exactly-bf16 data),
@@ -239,6 +242,16 @@ __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, 
     }
     // (softmax-group columns of a staged tile are flushed with whatever the stage holds and then rewritten by
     //  finish_groups, which runs after this kernel)
+    if (a.op.bits) {                  // block-uniform; lanes of the wave = 64 consecutive columns starting at a multiple of 64
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const unsigned long long m = __ballot(xf[i] != 0.f);
+            if ((threadIdx.x & 63) == 0 && b0 + i < a.Bp) {
+                uint32_t* q = a.op.bits + (int64_t)((col >> 6) << 1) * a.Bp + (b0 + i);      // word-major: [k >> 5][Bp]
+                q[0] = (uint32_t)m; q[a.Bp] = (uint32_t)(m >> 32);
+            }
+        }
+    }
     return lsum;
 }
 

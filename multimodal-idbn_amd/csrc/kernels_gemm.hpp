@@ -321,12 +321,26 @@ template <int NA>
 struct DownOperands {
     float wv[8];
     uint4 av[NA][2];
+    uint32_t ab[2];          // BITS: 32 activation bits (two K16 blocks x two halves) of batch rows r and 32 + r
 };
 
-template <bool UP, int NW, bool VEC4, int NA>
+// 8 activation bits -> the 8 bf16 values {0, 1} of an MFMA A fragment
+__device__ __forceinline__ uint4 bits_to_frag(uint32_t byte) {
+    uint32_t d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)byte, 2 * j, 1) & 0x3F80u;
+        d[j] = ((uint32_t)__builtin_amdgcn_sbfe((int)byte, 2 * j + 1, 1) & 0x3F800000u) | lo;
+    }
+    return make_uint4(d[0], d[1], d[2], d[3]);
+}
+
+template <bool UP, int NW, bool VEC4, int NA, bool BITS = false>
 __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int64_t ldw, int K, int N,
                                                 const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
-                                                const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33], int TR) {
+                                                const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33], int TR,
+                                                const uint32_t* __restrict__ abits = nullptr, int ldbits = 0) {
+    static_assert(!BITS || NA == 1, "bit-packed activations are single-term");
     constexpr int D = 4;                     // operand ring depth: D x (2 KB weights + activations) in flight per wave
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, hh = l >> 5;
     // the block owns output columns [n0, n0 + TR), TR <= 32 (host: plan_down_rows); MFMA lanes >= TR repeat the last
@@ -357,23 +371,41 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
 #pragma unroll
             for (int j = 0; j < 8; ++j) o.wv[j] = wrow[min(k0 + j, K - 1)];
         }
+        if constexpr (BITS) {
+            // one dword = this row's bits of K columns 32*(kb>>5) .. +31; byte 2*((kb>>4)&1) + hh is this lane's fragment
+            o.ab[0] = abits[(int64_t)(kbc >> 5) * fa.Bp + arow0];
+            o.ab[1] = abits[(int64_t)(kbc >> 5) * fa.Bp + arow1];
+            const int sh = 8 * (2 * ((kbc >> 4) & 1) + hh);
+            o.ab[0] = (o.ab[0] >> sh) & 0xFFu; o.ab[1] = (o.ab[1] >> sh) & 0xFFu;
+        } else {
 #pragma unroll
-        for (int ta = 0; ta < NA; ++ta) {
-            if (fa.dbg & 8) { o.av[ta][0] = make_uint4(kb, 0, 0, 0); o.av[ta][1] = make_uint4(0, kb, 0, 0); continue; }
-            o.av[ta][0] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow0) * 16 + 8 * hh);
-            o.av[ta][1] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow1) * 16 + 8 * hh);
+            for (int ta = 0; ta < NA; ++ta) {
+                if (fa.dbg & 8) { o.av[ta][0] = make_uint4(kb, 0, 0, 0); o.av[ta][1] = make_uint4(0, kb, 0, 0); continue; }
+                o.av[ta][0] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow0) * 16 + 8 * hh);
+                o.av[ta][1] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow1) * 16 + 8 * hh);
+            }
         }
     };
     auto compute = [&](const DownOperands<NA>& o) {
         uint4 bf[NW];
         make_w_frags<NW>(o.wv, bf);
+        if constexpr (BITS) {
 #pragma unroll
-        for (int ta = 0; ta < NA; ++ta)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt) {
+                const uint4 af = bits_to_frag(o.ab[mt]);
 #pragma unroll
                 for (int tw = 0; tw < NW; ++tw)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(o.av[ta][mt]), as_frag(bf[tw]), acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af), as_frag(bf[tw]), acc[mt], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int tw = 0; tw < NW; ++tw)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(o.av[ta][mt]), as_frag(bf[tw]), acc[mt], 0, 0, 0);
+        }
     };
     // K blocks are dealt to the waves in groups of D CONSECUTIVE blocks (group g of wave w = blocks
     // (4g+w)*D .. +D-1), so one pass over the ring reads D*64 B = 256 contiguous bytes of every weight row
@@ -393,7 +425,7 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             __builtin_amdgcn_sched_barrier(0);
-            if (fa.dbg & 4) acc[0][0] += ring[d].wv[0] + ring[d].wv[7] + __uint_as_float(ring[d].av[0][0].x) + __uint_as_float(ring[d].av[0][1].w);
+            if (!BITS && (fa.dbg & 4)) acc[0][0] += ring[d].wv[0] + ring[d].wv[7] + __uint_as_float(ring[d].av[0][0].x) + __uint_as_float(ring[d].av[0][1].w);
             else if ((4 * g + w) * D + d < nblk) compute(ring[d]);             // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
             load(ring[d], 16 * ((4 * (g + 1) + w) * D + d));              // refill the slot for the next group
@@ -444,17 +476,28 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     }
 }
 
-template <int NW, bool VEC4>
+// NAK = activation terms known to the host (1 or 3; 0 = decide per block from the exactness map), BITS = the
+// activations are the bit-packed sampled states.  One body per instantiation: several bodies inlined into one kernel
+// make the register allocator spill (scratch) in the hot loop.
+template <int NW, bool VEC4, int NAK, bool BITS>
 __global__ __launch_bounds__(256, 2) void gemm_down_fused(
     const float* __restrict__ W, int64_t ldw, int K, int N,
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
-    const FinishArgs fa, int tile_rows) {
+    const FinishArgs fa, int tile_rows, const uint32_t* __restrict__ abits, int ldbits) {
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
     stamp((fa.dbg & 128) != 0, blockIdx.z * gridDim.x + blockIdx.x, 0);
-    const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
-    if (na == 1) down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
-    else         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+    if constexpr (BITS) {
+        down_fused_body<false, NW, VEC4, 1, true>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, abits, ldbits);
+    } else if constexpr (NAK == 1) {
+        down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+    } else if constexpr (NAK == 3) {
+        down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+    } else {
+        const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
+        if (na == 1) down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+        else         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+    }
 }
 
 // K1 fused with its epilogue for SHORT visible dimensions (K = V <= 1024: joint RBM, chains): same

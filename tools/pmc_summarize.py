@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc_{FETCH_SIZE,WRITE_SIZE}/**/counter_collection.csv -> profiles/r01_pmc_hbm_traffic.json
+(HBM bytes per launch per kernel; gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request)."""
+import collections, csv, glob, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+res = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = sorted(glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_{c}/**/*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    if not fs:
+        sys.exit(f"no csv for {c}")
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[-1])):
+        if r.get("Counter_Name") == c and "imdbn" in r["Kernel_Name"]:
+            k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]
+            acc[k].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        res[k][f"{c}_KB_mean"] = sum(v) / len(v)
+        res[k]["launches"] = len(v)
+for k, d in res.items():
+    d["hbm_bytes_per_launch"] = (2 * d.get("FETCH_SIZE_KB_mean", 0.0) + d.get("WRITE_SIZE_KB_mean", 0.0)) * 1024
+out = {
+    "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} (separate passes) -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline",
+    "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950: FETCH_SIZE counts 64 B per 128-B request]",
+    "history": "before 128-B row pitch + XCD-aware K3 block map: K3 294 MB, K1 102 MB, K2 75 MB per launch",
+    "kernels": dict(res),
+}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json"), "w"), indent=1)
+for k, d in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+    print(f"{k[:60]:60s} {d['hbm_bytes_per_launch']/1e6:9.1f} MB/launch  x{d['launches']}")

@@ -138,10 +138,17 @@ struct FinishArgs {
     int dbg;                                       // timing experiments only: 1 = skip epilogue, 2 = skip GEMM loop
 };
 
+// gs / ge are only ever indexed with compile-time constants: a dynamically indexed member pins the whole struct in
+// memory (scratch, when it is a patched local copy as in the persistent chain kernel) instead of registers
 __device__ __forceinline__ bool in_group(const FinishArgs& a, int col) {
     bool g = false;
-    for (int i = 0; i < a.n_groups; ++i) g |= (col >= a.gs[i] && col < a.ge[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g |= (i < a.n_groups) && (col >= a.gs[i] && col < a.ge[i]);
     return g;
+}
+__device__ __forceinline__ void group_bounds(const FinishArgs& a, int g, int& s, int& e) {
+    s = g == 0 ? a.gs[0] : (g == 1 ? a.gs[1] : (g == 2 ? a.gs[2] : a.gs[3]));
+    e = g == 0 ? a.ge[0] : (g == 1 ? a.ge[1] : (g == 2 ? a.ge[2] : a.ge[3]));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -360,12 +367,15 @@ __global__ __launch_bounds__(256) void finish(const FinishArgs a) {
 //           column-sum partial of the octet ([Bp/8][N] layout of the main epilogue), squared error
 constexpr int GROUP_WMAX = 256;
 
-__global__ __launch_bounds__(256) void finish_groups(const FinishArgs a, int loss_slot0) {
+// one softmax group g x one 64-row batch chunk rb (of nrb); a whole block
+__device__ __forceinline__ void finish_groups_body(const FinishArgs& a, int loss_slot0, int g, int rb, int nrb) {
     __shared__ float sL[64][GROUP_WMAX + 1];
     __shared__ float rmx[64], rsum[64];
     __shared__ int ridx[64];
     __shared__ float sh[256];
-    const int g = blockIdx.x, rb = blockIdx.y, s = a.gs[g], e = a.ge[g], wd = e - s;
+    int s, e;
+    group_bounds(a, g, s, e);
+    const int wd = e - s;
     const int tid = threadIdx.x;
     for (int it = tid; it < 64 * wd; it += 256) {
         const int row = it / wd, j = it - row * wd;
@@ -451,9 +461,13 @@ __global__ __launch_bounds__(256) void finish_groups(const FinishArgs a, int los
         if (tid == 0) {
             float t = 0.f;
             for (int i = 0; i < 256; ++i) t += sh[i];
-            a.loss_part[loss_slot0 + g * gridDim.y + rb] = t;
+            a.loss_part[loss_slot0 + g * nrb + rb] = t;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void finish_groups(const FinishArgs a, int loss_slot0) {
+    finish_groups_body(a, loss_slot0, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // Caller tensor -> operand forms.  With `mix`: x = vk*m + (1-m)*U  (chain initial state,

@@ -339,14 +339,15 @@ template <bool UP, int NW, bool VEC4, int NA, bool BITS = false>
 __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int64_t ldw, int K, int N,
                                                 const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
                                                 const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33], int TR,
-                                                const uint32_t* __restrict__ abits = nullptr, int ldbits = 0) {
+                                                const uint32_t* __restrict__ abits, int ldbits,
+                                                int bx, int bz, int nbx /* tile (bx of nbx, batch chunk bz): blockIdx in the plain kernels */) {
     static_assert(!BITS || NA == 1, "bit-packed activations are single-term");
     constexpr int D = 4;                     // operand ring depth: D x (2 KB weights + activations) in flight per wave
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, hh = l >> 5;
     // the block owns output columns [n0, n0 + TR), TR <= 32 (host: plan_down_rows); MFMA lanes >= TR repeat the last
     // column (same addresses -> no extra traffic) and their results are dropped
     const int r = l & 31, rc = min(r, TR - 1);
-    const int n0 = blockIdx.x * TR, mb = blockIdx.z * 64;
+    const int n0 = bx * TR, mb = bz * 64;
     f32x16 acc[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -412,7 +413,7 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     // (whole 128-B lines per wave instead of lines split between waves).  Register ring, static slots.
     DownOperands<NA> ring[D];
     const int nblk = lda / 16;
-    const int sblk = blockIdx.z * gridDim.x + blockIdx.x;
+    const int sblk = bz * nbx + bx;
     const bool st = (fa.dbg & 128) != 0;
     stamp(st, sblk, 1);
     // epilogue side inputs (bias, loss reference, clamp / mu planes) of this thread's column x 8 rows: issued now,
@@ -472,7 +473,7 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
         const float t = wave_sum(lsum);
         if (l == 0) red[w] = t;
         __syncthreads();
-        if (tid == 0) fa.loss_part[blockIdx.z * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        if (tid == 0) fa.loss_part[bz * nbx + bx] = ((red[0] + red[1]) + red[2]) + red[3];
     }
 }
 
@@ -488,15 +489,15 @@ __global__ __launch_bounds__(256, 2) void gemm_down_fused(
     __shared__ float tile[64][33];
     stamp((fa.dbg & 128) != 0, blockIdx.z * gridDim.x + blockIdx.x, 0);
     if constexpr (BITS) {
-        down_fused_body<false, NW, VEC4, 1, true>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, abits, ldbits);
+        down_fused_body<false, NW, VEC4, 1, true>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, abits, ldbits, blockIdx.x, blockIdx.z, gridDim.x);
     } else if constexpr (NAK == 1) {
-        down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+        down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
     } else if constexpr (NAK == 3) {
-        down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+        down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
     } else {
         const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
-        if (na == 1) down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
-        else         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows);
+        if (na == 1) down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
+        else         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
     }
 }
 
@@ -510,8 +511,8 @@ __global__ __launch_bounds__(256, 2) void gemm_up_fused(
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
     const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
-    if (na == 1) down_fused_body<true, NW, false, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, 32);
-    else         down_fused_body<true, NW, false, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, 32);
+    if (na == 1) down_fused_body<true, NW, false, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, 32, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
+    else         down_fused_body<true, NW, false, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, 32, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------

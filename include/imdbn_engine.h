@@ -135,6 +135,11 @@ int imdbn_rbm_prop_up(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int 
                       imdbn_rng* rng, float* out_prob, int64_t ldo, float* out_sample, int64_t lds,
                       void* ws, size_t ws_bytes, imdbn_stream_t stream);
 
+/* ---- free energy   F(v) = -v.b - sum_j softplus(c_j + (vW)_j)   (imdbn/utils/energy_utils.py:19-28; the
+ *      `joint_rbm.free_energy` that imdbn.py:455-474 probes for and the reference never defines) -------- */
+int imdbn_rbm_free_energy(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B, float* out_F,
+                          void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
 /* ---- K2: p(v|h)   replaces RBM.visible_probs / backward (rbm.py:94-116,137-151) -------- */
 /* out_prob[B][V] = sigmoid((h W^T + b)/T) with softmax over each group; if logits_only: raw logits */
 int imdbn_rbm_prop_down(const imdbn_rbm_desc* d, const float* h, int64_t ldh, int B, float T,

@@ -662,6 +662,22 @@ int imdbn_rbm_prop_up(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int 
     return c.rng.finish();
 }
 
+int imdbn_rbm_free_energy(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B, float* out_F, void* ws, size_t ws_bytes,
+                          imdbn_stream_t stream) {
+    CHK(check_desc(d, false));
+    if (!v || !out_F || ldv < d->V) return fail(IMDBN_E_INVALID, "free_energy: bad tensor argument");
+    Ctx c(d, nullptr, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    CHK(prep(c, v, ldv, d->V, c.L.vis_rm[0], c.L.Vpad, nullptr, c.L.flags));
+    FinishArgs f = new_finish();
+    f.logits_only = 1;                                     // x = v W + c
+    f.out_prob = c.L.f_h; f.ld_prob = d->H;
+    CHK(prop(c, true, OpIn{c.L.vis_rm[0], c.nw == 1 ? 1 : 0, c.L.flags}, f));
+    hipLaunchKernelGGL(free_energy_rows, dim3(B), dim3(256), 0, c.s, v, ldv, d->vis_bias, d->V, c.L.f_h, (int64_t)d->H, d->H, out_F);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int imdbn_rbm_prop_down(const imdbn_rbm_desc* d, const float* h, int64_t ldh, int B, float T, int logits_only,
                         float* out_prob, int64_t ldo, void* ws, size_t ws_bytes, imdbn_stream_t stream) {
     CHK(check_desc(d, false));

@@ -525,6 +525,28 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
     }
 }
 
+// Free energy of visible configurations (imdbn/utils/energy_utils.py:19-28):
+//   F(v) = -sum_i v_i b_i - sum_j softplus(c_j + (v W)_j),  softplus as torch (x > 20 ? x : log1p(exp(x)))
+// one block per batch row; x = pre-activations [B][H] from the K1 path (logits_only); fixed-order tree sums.
+__global__ __launch_bounds__(256) void free_energy_rows(const float* __restrict__ v, int64_t ldv, const float* __restrict__ vis_bias, int V,
+                                                        const float* __restrict__ x, int64_t ldx, int H, float* __restrict__ out) {
+    __shared__ float sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    for (int i = tid; i < V; i += 256) acc += v[(int64_t)b * ldv + i] * vis_bias[i];
+    for (int j = tid; j < H; j += 256) {
+        const float t = x[(int64_t)b * ldx + j];
+        acc += t > 20.0f ? t : log1pf(expf(t));
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) sh[tid] += sh[tid + s2];
+        __syncthreads();
+    }
+    if (tid == 0) out[b] = -sh[0];
+}
+
 // rbm.py:216-226.  parts are [P][len] column-sum partials; loss parts are summed in double.
 struct BiasArgs {
     float* hid_bias; float* hb_m; int H; const float* hpos; const float* hneg;

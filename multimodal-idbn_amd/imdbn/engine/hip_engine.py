@@ -174,6 +174,16 @@ class HipEngine:
             return out, smp
         return out
 
+    def free_energy(self, rbm, v):
+        d = self._desc(rbm, False)
+        v = _f32c(v, "v")
+        B, dev = v.size(0), v.device
+        out = torch.empty(B, device=dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_free_energy(C.byref(d), _ptr(v), v.stride(0), B, _ptr(out), _ptr(ws), ws.numel(),
+                                                 self._stream(dev)), "imdbn_rbm_free_energy")
+        return out
+
     def prop_down(self, rbm, h, T=1.0, logits_only=False):
         d = self._desc(rbm, False)
         h = _f32c(h, "h")

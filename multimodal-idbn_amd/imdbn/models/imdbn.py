@@ -83,6 +83,12 @@ class iMDBN(nn.Module):
 
         self.joint_cd = int(self.params.get("JOINT_CD", self.params.get("CD", 1)))  # imdbn.py:164-167
         self.cross_steps = int(self.params.get("CROSS_GIBBS_STEPS", 50))
+        # Best-of-K refinement of the TXT->IMG chain (imdbn.py:451-474).  The reference's selection is inert (no
+        # RBM.free_energy -> all energies 0 -> candidate 0); that stays the default.  Opt in with
+        # CROSS_LIVE_BEST_OF_K=True (K from CROSS_BEST_OF_K, reference buffer size 5): the K-1 one-step refinement
+        # passes are computed, every candidate gets its free energy and each row keeps its lowest-energy candidate.
+        self.live_best_of_k = bool(self.params.get("CROSS_LIVE_BEST_OF_K", False))
+        self.best_of_k = int(self.params.get("CROSS_BEST_OF_K", KBUF))
         self.aux_every_k = int(self.params.get("JOINT_AUX_EVERY_K", 0))
         self.aux_cond_steps = int(self.params.get("JOINT_AUX_COND_STEPS", 50))
         self.features = None
@@ -235,13 +241,34 @@ class iMDBN(nn.Module):
             jr._mu_pull = None
         v_chain = jr.noisy_meanfield_annealed(v_known=v_known, known_mask=km, n_steps=steps, T0=3.0, T1=1.0,
                                               sigma0=0.9, hot_frac=0.7, sharpen_last=3, T_cold_plus=0.9)
-        # dead refinement passes (:460-474): each would draw one U[B,V] at its chain init (rbm.py:333)
-        _E.get_engine(jr.W.data).skip_draws(_E.get_rng(), [("u", V)] * (KBUF - 1), B)
+        if getattr(self, "live_best_of_k", False):
+            v_chain = self._best_of_k(v_chain, km, max(1, int(getattr(self, "best_of_k", KBUF))))[0]
+        else:
+            # dead refinement passes (:460-474): each would draw one U[B,V] at its chain init (rbm.py:333)
+            _E.get_engine(jr.W.data).skip_draws(_E.get_rng(), [("u", V)] * (KBUF - 1), B)
         jr._mu_pull = None                                                          # :476
         z_from_y = v_chain[:, :Dz]
         if hasattr(self, "z_affine_scale") and hasattr(self, "z_affine_bias"):       # :481-484
             z_from_y = (z_from_y - self.z_affine_bias) / (self.z_affine_scale + 1e-6)
         return self.image_idbn.decode(z_from_y), p_y_given_img
+
+    @torch.no_grad()
+    def _best_of_k(self, v_chain: torch.Tensor, km: torch.Tensor, K: int):
+        """Live version of imdbn.py:451-474: K-1 one-step refinements (T=0.9, no noise), free energy of every
+        candidate, per-row argmin, device-side gather (the reference gathers with a Python loop over rows).
+        Returns (v_pick [B,V], candidates [K,B,V], energies [K,B])."""
+        jr = self.joint_rbm
+        cands, energies = [v_chain], [jr.free_energy(v_chain)]
+        for _ in range(K - 1):
+            v_last = jr.noisy_meanfield_annealed(v_known=cands[-1], known_mask=km, n_steps=1, T0=0.9, T1=0.9,
+                                                 sigma0=0.0, hot_frac=0.0, sharpen_last=0, T_cold_plus=0.9)
+            cands.append(v_last)
+            energies.append(jr.free_energy(v_last))
+        cands = torch.stack(cands, dim=0)
+        energies = torch.stack(energies, dim=0)
+        best = energies.argmin(dim=0)                                     # first minimum, as torch.argmin in the reference
+        v_pick = cands[best, torch.arange(cands.size(1), device=cands.device)]
+        return v_pick, cands, energies
 
     @torch.no_grad()
     def represent(self, batch: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:

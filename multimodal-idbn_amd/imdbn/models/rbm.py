@@ -109,6 +109,15 @@ class RBM(nn.Module):
         return self._eng().prop_down(self, self._in(h), T=T)
 
     @torch.no_grad()
+    def free_energy(self, v: torch.Tensor) -> torch.Tensor:
+        """F(v) = -v.b - sum_j softplus(c_j + (vW)_j), shape [B] (imdbn/utils/energy_utils.py:19-28).
+
+        The reference's ``RBM`` has no such method (``iMDBN._cross_reconstruct`` probes for it with ``hasattr``,
+        imdbn.py:455, and falls back to zeros); here it exists and feeds the opt-in live best-of-K selection
+        (``iMDBN.live_best_of_k``)."""
+        return self._eng().free_energy(self, self._in(v))
+
+    @torch.no_grad()
     def sample_visible(self, v_prob: torch.Tensor) -> torch.Tensor:
         """Bernoulli over all columns, one categorical per softmax group (rbm.py:125-135)."""
         return self._eng().sample_visible(self, self._in(v_prob), _E.get_rng())

@@ -88,6 +88,9 @@ class OracleEngine:
             return self._t(p), self._t(h)
         return self._t(p)
 
+    def free_energy(self, rbm, v):
+        return self._t(O.free_energy(self._state(rbm), _np(v)))
+
     def prop_down(self, rbm, h, T=1.0, logits_only=False):
         st = self._state(rbm)
         return self._t(O.visible_logits(st, _np(h), T) if logits_only else O.visible_probs(st, _np(h), T))

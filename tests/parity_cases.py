@@ -251,3 +251,38 @@ def case_imdbn_small(dev, rel=3e-4):
     assert len(mdl.joint_history) == m["joint_epochs"]
     assert all(0.0 <= h["text_top1"] <= h["text_top3"] <= 1.0 for h in mdl.joint_history)
     return mdl
+
+
+def case_live_best_of_k(dev, V=150, H=48, Dz=140, B=9, K=7, rel=1e-4):
+    """Opt-in live best-of-K: free energies match the oracle, every row keeps its
+    lowest-energy candidate, the default (reference-identical, inert) path is untouched by the flag being off."""
+    import oracle.rbm_oracle as O
+    g = np.random.default_rng(5)
+    X = (g.random((B * 2, 100)) > 0.8).astype(F32)
+    Y = np.eye(V - Dz, dtype=F32)[np.arange(B * 2) % (V - Dz)]
+    dl = loader(X, Y, B)
+    params = {"LEARNING_RATE": 0.1, "WEIGHT_PENALTY": 1e-4, "INIT_MOMENTUM": 0.5, "FINAL_MOMENTUM": 0.95,
+              "LEARNING_RATE_DYNAMIC": True, "CD": 1, "CROSS_GIBBS_STEPS": 6, "CROSS_LIVE_BEST_OF_K": True, "CROSS_BEST_OF_K": K}
+    mdl = iMDBN([100, Dz], H, params=params, dataloader=dl, val_loader=dl, device=torch.device(dev), num_labels=V - Dz)
+    from oracle.draws import DrawStream
+    s = DrawStream(7)
+    W0 = (s.normal((V, H)) / F32(np.sqrt(V))).astype(F32)
+    hb = (s.normal((H,)) * F32(0.1)).astype(F32); vb = (s.normal((V,)) * F32(0.1)).astype(F32)
+    set_params(mdl.joint_rbm, dev, W0, hb, vb)
+    st = O.RBMState.create(W0, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=[(Dz, V)], hid_bias=hb, vis_bias=vb)
+    assert mdl.live_best_of_k and mdl.best_of_k == K
+    z = g.random((B, Dz), dtype=F32)
+    y = Y[:B]
+    vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+    vk[:, Dz:] = y; km[:, Dz:] = 1
+    with E.use_rng(E.ReplayRng(DrawStream(3))):
+        v0 = mdl.joint_rbm.noisy_meanfield_annealed(T(vk, dev), T(km, dev), n_steps=5)
+        pick, cands, en = mdl._best_of_k(v0, T(km, dev), K)
+    cands, en, pick = N(cands), N(en), N(pick)
+    assert cands.shape == (K, B, V) and en.shape == (K, B)
+    for k in range(K):
+        assert_close(en[k], O.free_energy(st, cands[k]), rel, f"free energy of candidate {k}")
+    best = en.argmin(0)
+    np.testing.assert_array_equal(pick, cands[best, np.arange(B)])
+    # the refinement is a deterministic mean-field step: candidate k+1 = one clamped down(up(.)) pass at T = 0.9
+    return en

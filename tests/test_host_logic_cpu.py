@@ -32,6 +32,10 @@ def test_imdbn_small_host_logic():
     P.case_imdbn_small("cpu", rel=2e-4)
 
 
+def test_live_best_of_k_host_logic():
+    P.case_live_best_of_k("cpu")
+
+
 def test_product_refuses_cpu_without_engine():
     """No silent CPU fallback: without the test double a CPU tensor must raise."""
     E.set_engine_for_testing(None)

@@ -116,6 +116,21 @@ def test_philox_chains_and_clamped_match_oracle(B):
         assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
 
 
+@pytest.mark.parametrize("V,H,B", [(150, 48, 5), (532, 256, 64), (1500, 500, 33)])
+def test_free_energy_matches_oracle(V, H, B):
+    """imdbn_rbm_free_energy against F(v) = -v.b - sum softplus(c + vW) (energy_utils.py:19-28); both K1 forms
+    (fused short-K and split-K + finish) are covered by the shapes."""
+    r, st, g = _mk(V, H, None, seed=4)
+    v = g.random((B, V), dtype=F32)
+    v[:, ::3] = (v[:, ::3] > 0.5)
+    assert_close(P.N(r.free_energy(P.T(v, DEV))), O.free_energy(st, v), 1e-5, "free energy")
+
+
+def test_live_best_of_k_gpu():
+    en = P.case_live_best_of_k(DEV, K=16)
+    assert en.shape[0] == 16
+
+
 def test_products_are_fp32_exact():
     """bf16x3 split: v@W against float64 must be at fp32 rounding level (not bf16 level)."""
     r, st, g = _mk(2000, 300, None, seed=11)

@@ -57,4 +57,6 @@ m = iMDBN([10000, 1500, 500], 256, params=dict(PARAMS), dataloader=dl, val_loade
 m.z_class_mean = torch.rand(32, 500, device=dev)
 z5 = torch.rand(256, 500, device=dev); y5 = torch.eye(32, device=dev)[torch.randint(0, 32, (256,), device=dev)]
 out["C5_cross_reconstruct_ms"] = 1e3 * timeit(lambda: m._cross_reconstruct(z5, y5, steps=50), 10); out["C5_ref_cpu_ms"] = 263.0
+m.live_best_of_k, m.best_of_k = True, 16      # K=16 with live free-energy selection
+out["C5_cross_reconstruct_live_k16_ms"] = 1e3 * timeit(lambda: m._cross_reconstruct(z5, y5, steps=50), 10)
 print(json.dumps(out))

@@ -9,7 +9,8 @@ K1 -> K2 -> K1 -> K3 (+ epilogue kernels), called through the product's Python c
 ``iDBN.train`` calls it (idbn.py:202).  Inputs (16 distinct synthetic binary 100x100 "dot" frames
 batches, density 0.1) are resident in HBM before the timed region.  With N>1 each rank holds a
 full parameter replica and 64 rows of a 64*N global batch; one all-reduce (RCCL) of the packed
-statistics per step; `value` counts global updates per second (weak scaling).
+statistics per step; `value` counts batch-64 updates per second summed over the ranks (= N x global steps/s,
+weak scaling: 64 rows per GPU).
 
 One JSON line on rank 0.  `roofline` is for the dominant kernel (K3 assoc_update): algorithmic bytes
 16*V*H per launch over the HIP-event-measured mean launch time on the launch stream.
@@ -174,7 +175,9 @@ def main():
     assert torch.isfinite(loss).item(), "loss is not finite"
 
     if rank == 0:
-        ups = args.steps / dt
+        # unit = one batch-64 CD-1 update; every rank processes one per step (the step updates the shared weights
+        # with the 64*N-row global batch), so the whole job processes N units per step
+        ups = world * args.steps / dt
         out = {
             "metric": "CD-1 updates/sec (batch 64, 10000<->1500 RBM)",
             "value": ups, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,10 +189,11 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
                        "final_loss": float(loss)},
+            "global_steps_per_s": args.steps / dt,
             "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
             "host_enqueue_us_p50_max": _p50_max(t0, stamps),
-            "frac_hbm_roofline_whole_step": ups * 16.0 * V * H / (HBM_PEAK_GBS * 1e9),
-            "frac_bf16_mfma_roofline_whole_step": ups * 10.0 * B * V * H / (BF16_PEAK_TFLOPS * 1e12),
+            "frac_hbm_roofline_whole_step": (ups / world) * 16.0 * V * H / (HBM_PEAK_GBS * 1e9),
+            "frac_bf16_mfma_roofline_whole_step": (ups / world) * 10.0 * B * V * H / (BF16_PEAK_TFLOPS * 1e12),
         }
         if world == 1 and k3_n > 0:
             avg_s = 1e-3 * k3_ms / k3_n

@@ -137,9 +137,11 @@ def main():
 
     torch.manual_seed(0)
     rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
-    if world > 1:      # identical replicas
+    if world > 1:      # identical replicas (W lives in a row-padded buffer: broadcast a contiguous copy)
         for t in (rbm.W.data, rbm.hid_bias.data, rbm.vis_bias.data):
-            dist.broadcast(t, 0)
+            c = t.contiguous()
+            dist.broadcast(c, 0)
+            t.copy_(c)
     g = torch.Generator(device="cpu").manual_seed(1 + rank)
     batches = [(torch.rand(B, V, generator=g) > 0.9).float().to(dev) for _ in range(16)]
     E.set_rng(E.PhiloxRng(seed=2, row0=rank * B))

@@ -15,6 +15,7 @@
 #include "../../include/imdbn_engine.h"
 #include "kernels_ew.hpp"
 #include "kernels_gemm.hpp"
+#include "kernels_chain.hpp"
 
 using namespace imdbn;
 
@@ -25,6 +26,8 @@ int g_ks_up = 0, g_ks_down = 0;
 bool g_no_fast_k3 = false;
 bool g_no_fast_k1 = false;
 bool g_no_fused_up = false;
+int g_k4_rows = 0;          // tuning: batch rows per chain-kernel block (0 = automatic)
+int g_no_chain_kernel = 0;  // testing: run chains as one launch per half step
 int g_no_bits = 0;  // testing: never use the bit-packed hidden operand
 int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
 int g_dbg = 0;    // tuning/testing: force the generic K3
@@ -91,6 +94,8 @@ struct Layout {
     float* f_v[2];
     float* cs_hpos; float* cs_hneg; float* cs_vpos; float* cs_vneg;
     float* loss_part; int n_loss_slots;
+    ChainRec* chain_recs;   // per-step schedule of the row-parallel chain kernel
+    bf16_t* k4_planes; int64_t k4_plane_stride;      // fragment-ordered bf16 weight planes [2 directions][3 terms]
     int down_tr;            // visible rows per block of the fused K2 (<= 32): balances the row tiles over the CUs
     size_t bytes;
 };
@@ -159,6 +164,12 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.cs_vneg = (float*)take((size_t)L.P * V * 4);
     L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 16) * (L.Bp / 64)) + IMDBN_MAX_GROUPS * (L.Bp / 64);
     L.loss_part = (float*)take((size_t)L.n_loss_slots * 4);
+    L.chain_recs = (ChainRec*)take(sizeof(ChainRec) * CHAIN_MAX_STEPS);
+    L.k4_plane_stride = 0; L.k4_planes = nullptr;
+    if (V <= 1024 && H <= 1024) {
+        L.k4_plane_stride = (int64_t)std::max(cdiv(H, 16) * cdiv(V, 32), cdiv(V, 16) * cdiv(H, 32)) * 512;
+        L.k4_planes = (bf16_t*)take((size_t)6 * L.k4_plane_stride * 2);
+    }
     L.bytes = off;
     return L;
 }
@@ -370,12 +381,12 @@ int n_loss_used(const Ctx& c, bool up) {
 
 // caller fp32 tensor -> operand forms in the workspace
 int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_t* tr, int* flag,
-         float* colsum = nullptr) {
+         float* colsum = nullptr, int terms = 3) {
     PrepArgs p;
     memset(&p, 0, sizeof(p));
     p.in = in; p.ld = ld; p.B = c.L.B; p.Bp = c.L.Bp; p.N = N;
-    p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = 3; p.op.Bp = c.L.Bp;
-    p.op.tr = tr; p.op.tr_ts = (int64_t)N * c.L.Bp; p.op.tr_terms = 3;
+    p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = terms; p.op.Bp = c.L.Bp;
+    p.op.tr = tr; p.op.tr_ts = (int64_t)N * c.L.Bp; p.op.tr_terms = terms;
     p.flag = flag;
     p.colsum_part = colsum;
     hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(N, ldrm), 64), c.L.P), dim3(256), 0, c.s, p);
@@ -504,6 +515,71 @@ int launch_bias(Ctx& c, const BiasArgs& b) {
     return 0;
 }
 
+// ---- row-parallel chain kernel (kernels_chain.hpp) -------------------------------------------
+bool chain_kernel_ok(const Ctx& c, int n_steps) {
+    const Layout& L = c.L;
+    if (g_no_chain_kernel || !L.k4_planes || n_steps < 2 || n_steps > CHAIN_MAX_STEPS) return false;
+    if (c.d->n_groups > 1) return false;                   // the kernel keeps ONE softmax group's logits in LDS
+    const int gw = c.d->n_groups ? c.d->group_end[0] - c.d->group_start[0] : 0;
+    const size_t lds = (size_t)c.rt * K4_ROWS * ((rup(L.V, 32) + 8) + (rup(L.H, 32) + 8)) * 2      // activation terms
+                     + (size_t)K4_ROWS * (rup(std::max(L.V, L.H), 16) + 1) * 4                        // fp32 stage
+                     + (size_t)K4_ROWS * (gw + 1) * 4 + K4_ROWS * 16;                                  // group logits, row stats
+    return gw <= GROUP_WMAX && lds <= (size_t)K4_LDS_BYTES;
+}
+
+int run_chain_k4(Ctx& c, const float* vk, const float* mask, int64_t ldk, int n_steps, const imdbn_chain_step* st,
+                 const float* mu, int64_t ldmu, int Dz, float* out, int64_t ldo, bool want_stats) {
+    const Layout& L = c.L;
+    const imdbn_rbm_desc* d = c.d;
+    const int B = L.B;
+    // draw cursors in exactly the order of the per-launch path below
+    ChainRecBatch batch;
+    for (int t0 = 0; t0 < n_steps; t0 += CHAIN_REC_BATCH) {
+        const int n = std::min(CHAIN_REC_BATCH, n_steps - t0);
+        memset(&batch, 0, sizeof(batch));
+        for (int i = 0; i < n; ++i) {
+            const imdbn_chain_step& s = st[t0 + i];
+            ChainRec& r = batch.r[i];
+            r.T = s.T; r.sigma = s.sigma; r.eta = s.eta;
+            r.flags = (s.sample_h ? 1 : 0) | ((s.vmode & 3) << 1) | (s.clamp ? 8 : 0);
+            auto cd = [](const DrawSrc& x) { ChainDraw y; y.tape = x.tape; y.draw = x.draw; return y; };
+            if (s.sigma > 0.f) r.noise_h = cd(c.rng.floats(B, L.H));
+            if (s.sample_h) r.uni_h = cd(c.rng.floats(B, L.H));
+            if (s.sigma > 0.f) r.noise_v = cd(c.rng.floats(B, L.V));
+            if (s.vmode != 0) {
+                r.uni_v = cd(c.rng.floats(B, L.V));
+                DrawSrc cu; c.rng.cats(B, d->n_groups, &r.cat_tape, &cu);
+                r.cat_uni = cd(cu);
+            }
+        }
+        hipLaunchKernelGGL(chain_write_recs, dim3(1), dim3(64), 0, c.s, batch, L.chain_recs + t0, n);
+    }
+    hipLaunchKernelGGL(k4_split_planes, dim3(std::max(cdiv(L.H, 16), cdiv(L.V, 16)), std::max(cdiv(L.V, 32), cdiv(L.H, 32)), 2), dim3(64), 0, c.s,
+                       d->W, d->ldw, L.V, L.H, c.nw, L.k4_planes, L.k4_plane_stride);
+    K4Args a;
+    memset(&a, 0, sizeof(a));
+    a.planes = L.k4_planes; a.plane_stride = L.k4_plane_stride;
+    a.V = L.V; a.H = L.H; a.B = B; a.nw = c.nw; a.rt = c.rt;
+    a.hid_bias = d->hid_bias; a.vis_bias = d->vis_bias;
+    a.n_groups = d->n_groups;
+    for (int g = 0; g < IMDBN_MAX_GROUPS; ++g) { a.gs[g] = d->group_start[g]; a.ge[g] = d->group_end[g]; }
+    a.state = out; a.lds = ldo;
+    a.recs = L.chain_recs; a.n_steps = n_steps;
+    a.seed = c.rng.r ? c.rng.r->seed : 0; a.row0 = c.rng.r ? c.rng.r->row0 : 0;
+    a.mu = mu; a.ldmu = ldmu; a.Dz = Dz;
+    a.vk = vk; a.mask = mask; a.ldk = ldk;
+    // rows per block: enough blocks to spread the per-element work (Philox, Box-Muller, sigmoid) over the CUs;
+    // one block per CU at most (every block streams all of W from L2)
+    a.rows = g_k4_rows > 0 ? g_k4_rows : (B <= 2 * cu_count() ? 2 : (B <= 4 * cu_count() ? 4 : (B <= 8 * cu_count() ? 8 : 16)));      // measured: 0.90 / 0.99 / 1.19 / 1.59 ms for 2 / 4 / 8 / 16 rows (30 steps, 532<->256)
+    if (c.nw == 3) hipLaunchKernelGGL(k4_chain<3>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);
+    else           hipLaunchKernelGGL(k4_chain<1>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);
+    HIPCHK(hipGetLastError());
+    // operand forms of the final state (what the last v|h launch of the per-launch path leaves behind)
+    CHK(prep(c, out, ldo, L.V, L.vis_rm[0], L.Vpad, want_stats ? L.vis_tr[0] : nullptr, nullptr, want_stats ? L.cs_vpos : nullptr, c.rt));
+    c.hid_bits_ok = false;
+    return 0;
+}
+
 // chain: init + steps.  The final state ends in fp32 `out` (ld ldo) and in vis_rm[0] (rt terms).
 // want_stats: additionally leave the transposed form in vis_tr[0] and column sums in cs_vpos.
 int run_chain(Ctx& c, const float* vk, const float* mask, int64_t ldk, int init_uniform, int n_steps,
@@ -526,6 +602,8 @@ int run_chain(Ctx& c, const float* vk, const float* mask, int64_t ldk, int init_
         hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Vpad, 64), L.P), dim3(256), 0, c.s, p);
         HIPCHK(hipGetLastError());
     }
+    if (chain_kernel_ok(c, n_steps))
+        return run_chain_k4(c, vk, mask, ldk, n_steps, st, mu, ldmu, Dz, out, ldo, want_stats);
     for (int t = 0; t < n_steps; ++t) {
         const imdbn_chain_step& s = st[t];
         const bool last = (t == n_steps - 1);
@@ -601,6 +679,8 @@ int imdbn_set_option(const char* name, int value) {
     else if (!strcmp(name, "ksplit_down")) g_ks_down = std::max(0, value);
     else if (!strcmp(name, "generic_k3")) g_no_fast_k3 = value != 0;
     else if (!strcmp(name, "down_rows")) { if (value != 0 && (value < 4 || value > 32 || value % 4)) return fail(IMDBN_E_INVALID, "down_rows must be 0 or a multiple of 4 in [4, 32]"); g_down_tr = value; }
+    else if (!strcmp(name, "no_chain_kernel")) g_no_chain_kernel = value;
+    else if (!strcmp(name, "chain_rows")) { if (value < 0 || value > 16) return fail(IMDBN_E_INVALID, "chain_rows must be in [0, 16]"); g_k4_rows = value; }
     else if (!strcmp(name, "no_bits")) g_no_bits = value;
     else if (!strcmp(name, "dbg")) g_dbg = value;
     else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;

@@ -1,0 +1,327 @@
+// Row-parallel persistent chain kernel ("K4").
+//
+// The Gibbs / mean-field chains of the joint RBM (rbm.py:240-400 conditional_gibbs*, noisy_meanfield_annealed; the
+// positive phase of train_epoch_clamped; imdbn.py:386-488 _cross_reconstruct) are 30-72 dependent half steps on a
+// small RBM (532 <-> 256).  As one launch per half step they are pure launch / kernel-boundary latency (~49 us per
+// step), and a grid-wide barrier costs as much as a launch on this part.  But batch rows never
+// interact inside a chain, so here a block owns a few batch rows and runs the WHOLE chain for them:
+//   * W is split once per call into bf16 hi/mid/lo planes in MFMA-fragment order for both directions
+//     (k4_split_planes: plane[dir][term][n-tile][k-block] = one contiguous KB = one wave load);
+//   * the visible / hidden activations of its rows live in LDS as bf16 terms (exact for fp32 values);
+//   * every half step streams the planes from L2 through v_mfma_f32_16x16x32_bf16 (8 waves split the 16-column
+//     output tiles behind a 6-deep register ring; measured at the L2->CU fill rate, ~117 GB/s), stages the raw sums
+//     in LDS and applies the same epilogue arithmetic as kernels_ew.hpp finish_rows / finish_groups, one element
+//     per thread;
+//   * only `rows` (4 or 8) of the 16 MFMA rows carry data: the element-wise work (Philox, Box-Muller, sigmoid) of a
+//     half step on ONE CU costs more than the GEMM, so the batch is spread over 4x more CUs instead;
+//   * the per-step schedule (temperature, noise, mu-pull, clamp, sampling, draw cursors) is a record array in the
+//     workspace; the final visible state leaves as fp32 and the caller re-derives the operand forms from it.
+// No inter-block communication, no barrier other than __syncthreads().
+#pragma once
+#include "kernels_ew.hpp"
+
+namespace imdbn {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ChainDraw { const float* tape; uint64_t draw; };
+struct ChainRec {                 // one chain step (imdbn_chain_step + the draw cursors the host assigned to it)
+    float T, sigma, eta;
+    int flags;                    // bit 0 sample_h | bits 1-2 vmode | bit 3 clamp
+    ChainDraw noise_h, uni_h, noise_v, uni_v, cat_uni;
+    const int32_t* cat_tape;
+};
+constexpr int CHAIN_REC_BATCH = 32;          // records per writer launch (kernel arguments are limited to 4 KB)
+constexpr int CHAIN_MAX_STEPS = 256;
+constexpr int K4_ROWS = 16;                  // batch rows per block (M of the MFMA)
+constexpr int K4_WAVES = 8;                  // 512 threads: two waves per SIMD, 256 registers each (no spills in the ring)
+constexpr int K4_THREADS = 64 * K4_WAVES;
+constexpr int K4_LDS_BYTES = 152 * 1024;
+struct ChainRecBatch { ChainRec r[CHAIN_REC_BATCH]; };
+
+__global__ void chain_write_recs(const ChainRecBatch b, ChainRec* dst, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = b.r[threadIdx.x];
+}
+
+// plane[dir][term]: NT x KB fragments of 64 lanes x 8 bf16.  dir 0 (h|v): n = hidden unit, k = visible unit;
+// dir 1 (v|h): n = visible unit, k = hidden unit.  Lane l of fragment (nt, kb) holds k = 32*kb + 8*(l>>4) + j,
+// n = 16*nt + (l&15): the B operand of v_mfma_f32_16x16x32_bf16.
+__global__ __launch_bounds__(64) void k4_split_planes(const float* __restrict__ W, int64_t ldw, int V, int H, int nw,
+                                                      bf16_t* __restrict__ planes, int64_t plane_stride) {
+    const int l = threadIdx.x, dir = blockIdx.z;
+    const int NT = dir == 0 ? (H + 15) / 16 : (V + 15) / 16, KB = dir == 0 ? (V + 31) / 32 : (H + 31) / 32;
+    const int nt = blockIdx.x, kb = blockIdx.y;
+    if (nt >= NT || kb >= KB) return;
+    const int n = 16 * nt + (l & 15), k0 = 32 * kb + 8 * (l >> 4);
+    uint32_t t[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        float x = 0.f;
+        if (dir == 0) { if (k < V && n < H) x = W[(int64_t)k * ldw + n]; }
+        else          { if (n < V && k < H) x = W[(int64_t)n * ldw + k]; }
+        if (nw == 3) split3(x, t[0][j], t[1][j], t[2][j]);
+        else { t[0][j] = bf16_rne(x); t[1][j] = 0u; t[2][j] = 0u; }
+    }
+    for (int tw = 0; tw < nw; ++tw) {
+        bf16_t* q = planes + (dir * 3 + tw) * plane_stride + ((int64_t)(nt * KB + kb) * 64 + l) * 8;
+        *reinterpret_cast<uint4*>(q) = make_uint4(t[tw][0] | (t[tw][1] << 16), t[tw][2] | (t[tw][3] << 16),
+                                                  t[tw][4] | (t[tw][5] << 16), t[tw][6] | (t[tw][7] << 16));
+    }
+}
+
+struct K4Args {
+    const bf16_t* planes; int64_t plane_stride;     // [2][3] planes
+    int V, H, B, nw, rt;                           // nw weight terms, rt terms of a real-valued activation
+    const float* hid_bias; const float* vis_bias;
+    int n_groups; int gs[4]; int ge[4];
+    float* state; int64_t lds;                     // fp32 visible state [B][V]: v0 in, final v out
+    int rows;                                      // batch rows per block (<= 16): fewer rows = more CUs share the element-wise work
+    const ChainRec* recs; int n_steps;
+    uint64_t seed; int64_t row0;
+    const float* mu; int64_t ldmu; int Dz;
+    const float* vk; const float* mask; int64_t ldk;
+};
+
+__device__ __forceinline__ DrawSrc k4_src(const K4Args& a, const ChainDraw& d, int N) {
+    DrawSrc s;
+    s.tape = d.tape; s.seed = a.seed; s.draw = d.draw; s.row0 = a.row0; s.N = N;
+    return s;
+}
+
+// value -> bf16 terms at act[t][row][col] (row pitch AK elements)
+__device__ __forceinline__ void k4_put(bf16_t* act, int AK, int terms, int row, int col, float x, bool exact1) {
+    if (exact1 || terms == 1) {
+        act[row * AK + col] = (bf16_t)bf16_rne(x);
+        if (terms == 3) { act[(K4_ROWS + row) * AK + col] = 0; act[(2 * K4_ROWS + row) * AK + col] = 0; }
+    } else {
+        uint32_t hi, mid, lo;
+        split3(x, hi, mid, lo);
+        act[row * AK + col] = (bf16_t)hi; act[(K4_ROWS + row) * AK + col] = (bf16_t)mid; act[(2 * K4_ROWS + row) * AK + col] = (bf16_t)lo;
+    }
+}
+
+// stage[16][SP] = act[16 x K] * plane[K x N].  Wave w owns the 16-column tiles w, w+16, ...; its (tile, k-block)
+// items form ONE flat sequence behind a K4_RING-deep register ring of B fragments (a k-block of one tile is only
+// 3-9 MFMAs: one block ahead is not enough to cover the L2 latency, measured 1.3 us per k-block).  na = activation
+// terms multiplied (1: the input is exactly bf16).  Accumulators leave in the C layout (lane l: column l&15,
+// rows 4*(l>>4)+r) at the end of each tile.
+// NW / NA are compile-time: a run-time `if (tw < nw)` puts a branch around every load and MFMA and the compiler then
+// waits vmcnt(0) before each MFMA (no overlap at all).
+constexpr int K4_RING = 6;
+template <int NW, int NA>
+__device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB, const bf16_t* act, int AK,
+                                        float* stage, int SP) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const bf16_t* pl = a.planes + (int64_t)dir * 3 * a.plane_stride;
+    const int my_tiles = w < NT ? (NT - w + K4_WAVES - 1) / K4_WAVES : 0;
+    const int n_items = my_tiles * KB;
+    uint4 ring[K4_RING][NW];
+    auto load = [&](uint4 (&b)[NW], int it) {
+        const int itc = min(it, n_items - 1);                            // clamped: surplus slots repeat the last item
+        const int nt = w + K4_WAVES * (itc / KB), kb = itc - (itc / KB) * KB;
+#pragma unroll
+        for (int tw = 0; tw < NW; ++tw)
+            b[tw] = *reinterpret_cast<const uint4*>(pl + tw * a.plane_stride + ((int64_t)(nt * KB + kb) * 64 + l) * 8);
+    };
+    if (n_items == 0) return;
+#pragma unroll
+    for (int d = 0; d < K4_RING; ++d) load(ring[d], d);
+    f32x4 acc[NW];                   // one accumulator per weight term: NW independent MFMA chains instead of one of 3*NW
+#pragma unroll
+    for (int tw = 0; tw < NW; ++tw) acc[tw] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kb = 0, nt = w;
+    // every ring slot is processed unconditionally (the item sequence is padded with repeats of the last item whose
+    // products are never stored): a conditional around the loads would make the compiler wait for vmcnt(0) at every
+    // use and serialise one L2 round trip per item (measured: 1.06 us per item)
+    for (int it0 = 0; it0 < n_items; it0 += K4_RING) {
+#pragma unroll
+        for (int d = 0; d < K4_RING; ++d) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ta = 0; ta < NA; ++ta) {
+                const uint4 af = *reinterpret_cast<const uint4*>(act + (ta * K4_ROWS + (l & 15)) * AK + 32 * min(kb, KB - 1) + 8 * (l >> 4));
+#pragma unroll
+                for (int tw = 0; tw < NW; ++tw)
+                    acc[tw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(ring[d][tw]), acc[tw], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load(ring[d], it0 + d + K4_RING);
+            if (++kb == KB) {                                             // tile finished (padding items never get here with a real tile)
+                if (it0 + d < n_items) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        float t = acc[NW - 1][rr];                         // smallest terms first
+#pragma unroll
+                        for (int tw = NW - 2; tw >= 0; --tw) t += acc[tw][rr];
+                        stage[(4 * (l >> 4) + rr) * SP + 16 * nt + (l & 15)] = t;
+                    }
+                }
+#pragma unroll
+                for (int tw = 0; tw < NW; ++tw) acc[tw] = f32x4{0.f, 0.f, 0.f, 0.f};
+                kb = 0; nt += K4_WAVES;
+            }
+        }
+    }
+}
+
+template <int NW>          // weight terms = terms of a real-valued activation (PARITY 3, FAST 1)
+__global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
+    __shared__ __attribute__((aligned(16))) char smem[K4_LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int RB = a.rows;                                                          // valid rows of this block; MFMA rows >= RB are zero
+    const int b0 = blockIdx.x * RB;
+    const int VK = (a.V + 31) / 32 * 32 + 8, HK = (a.H + 31) / 32 * 32 + 8;      // LDS row pitch (elements): 16-B skew against bank conflicts
+    constexpr int at = NW;                                                          // activation terms kept (= a.rt)
+    const int gs0 = a.gs[0], gwd = a.n_groups > 0 ? a.ge[0] - a.gs[0] : 0;          // the (single) softmax group
+    const int GW = gwd + 1;
+    const int SP = max((a.H + 15) / 16, (a.V + 15) / 16) * 16 + 1;                  // stage pitch (floats)
+    bf16_t* vact = reinterpret_cast<bf16_t*>(smem);                                 // [at][16][VK]
+    bf16_t* hact = vact + at * K4_ROWS * VK;                                        // [at][16][HK]
+    float* stage = reinterpret_cast<float*>(hact + at * K4_ROWS * HK);              // [16][SP] raw sums of the current half step
+    float* glog = stage + K4_ROWS * SP;                                             // [16][GW] group logits
+    float* gaux = glog + K4_ROWS * GW;                                              // [16][4] group max, sum, sampled index
+    const int NTu = (a.H + 15) / 16, KBu = (a.V + 31) / 32, NTd = (a.V + 15) / 16, KBd = (a.H + 31) / 32;
+
+    // v0 -> terms (pad columns and rows >= B are zero)
+    for (int i = tid; i < K4_ROWS * (VK - 8); i += K4_THREADS) {
+        const int row = i / (VK - 8), col = i - row * (VK - 8);
+        const float x = (col < a.V && row < RB && b0 + row < a.B) ? a.state[(int64_t)(b0 + row) * a.lds + col] : 0.f;
+        k4_put(vact, VK, at, row, col, x, false);
+    }
+    for (int i = tid; i < at * K4_ROWS * HK; i += K4_THREADS) hact[i] = 0;          // pad columns and rows >= RB stay zero for the whole chain
+    __syncthreads();
+
+    for (int t = 0; t < a.n_steps; ++t) {
+        const ChainRec r = a.recs[t];
+        const bool sample_h = (r.flags & 1) != 0, clamp = (r.flags & 8) != 0, last = t == a.n_steps - 1;
+        const int vmode = (r.flags >> 1) & 3;
+        const float T = fmaxf(r.T, 1e-6f);                       // max(1e-6, T)  rbm.py:92,96
+        const bool pull_on = a.mu && r.eta != 0.f;
+        // ---- h | v  (rbm.py:81-92) -----------------------------------------------------------------
+        k4_gemm<NW, NW>(a, 0, NTu, KBu, vact, VK, stage, SP);
+        __syncthreads();
+        {
+            const DrawSrc nz = k4_src(a, r.noise_h, a.H), un = k4_src(a, r.uni_h, a.H);
+            for (int i = tid; i < RB * a.H; i += K4_THREADS) {
+                const int row = i / a.H, col = i - row * a.H, bd = min(b0 + row, a.B - 1);
+                float x = stage[row * SP + col] + a.hid_bias[col];
+                if (T != 1.0f) x = x / T;
+                if (r.sigma > 0.f) x = x + draw_normal(nz, bd, col) * r.sigma;
+                float p = sigmoidf_ref(x);
+                if (sample_h) p = (p > draw_uniform(un, bd, col)) ? 1.f : 0.f;
+                k4_put(hact, HK, at, row, col, (b0 + row < a.B) ? p : 0.f, sample_h);
+            }
+        }
+        __syncthreads();
+        // ---- v | h  (rbm.py:94-135) ------------------------------------------------------------------
+        if (sample_h) k4_gemm<NW, 1>(a, 1, NTd, KBd, hact, HK, stage, SP);      // sampled states are exactly bf16: one term
+        else          k4_gemm<NW, NW>(a, 1, NTd, KBd, hact, HK, stage, SP);
+        __syncthreads();
+        {
+            const DrawSrc nz = k4_src(a, r.noise_v, a.V), un = k4_src(a, r.uni_v, a.V);
+            for (int i = tid; i < RB * a.V; i += K4_THREADS) {
+                const int row = i / a.V, col = i - row * a.V, b = b0 + row, bd = min(b, a.B - 1);
+                float x = stage[row * SP + col] + a.vis_bias[col];
+                if (T != 1.0f) x = x / T;
+                if (r.sigma > 0.f) x = x + draw_normal(nz, bd, col) * r.sigma;
+                if (gwd > 0 && col >= gs0 && col < gs0 + gwd) {              // softmax group: logits now, the rest below
+                    glog[row * GW + (col - gs0)] = x;
+                    continue;
+                }
+                float p = sigmoidf_ref(x);
+                if (pull_on && col < a.Dz) p = (1.0f - r.eta) * p + r.eta * a.mu[(int64_t)bd * a.ldmu + col];
+                const float m = clamp ? a.mask[(int64_t)bd * a.ldk + col] : 0.f;
+                const float kn = clamp ? a.vk[(int64_t)bd * a.ldk + col] : 0.f;
+                const float mixed = clamp ? (p * (1.0f - m) + kn * m) : p;
+                float v;
+                if (vmode == 0) v = mixed;
+                else {
+                    const float u = draw_uniform(un, bd, col);
+                    if (vmode == 1) { const float smp = (p > u) ? 1.f : 0.f; v = clamp ? (smp * (1.0f - m) + kn * m) : smp; }
+                    else v = (mixed > u) ? 1.f : 0.f;
+                }
+                if (b >= a.B) v = 0.f;
+                k4_put(vact, VK, at, row, col, v, false);
+                if (last && b < a.B) a.state[(int64_t)b * a.lds + col] = v;
+            }
+        }
+        if (gwd > 0) {
+            // softmax + categorical of the group (finish_groups_body arithmetic).  The exponentials and the clipped
+            // probabilities are computed by all threads; only the ORDERED sums (softmax denominator, inverse-CDF
+            // accumulation -- same order as the per-launch path and the oracle) stay with one thread per row.
+            __syncthreads();
+            if (tid < RB) {
+                float mx = -INFINITY;
+                for (int j = 0; j < gwd; ++j) mx = fmaxf(mx, glog[tid * GW + j]);
+                gaux[tid * 4 + 0] = mx;
+            }
+            __syncthreads();
+            for (int i = tid; i < RB * gwd; i += K4_THREADS) {
+                const int row = i / gwd, j = i - row * gwd;
+                glog[row * GW + j] = expf(glog[row * GW + j] - gaux[row * 4 + 0]);          // e_j
+            }
+            __syncthreads();
+            if (tid < RB) {
+                float sum = 0.f;
+                for (int j = 0; j < gwd; ++j) sum += glog[tid * GW + j];
+                gaux[tid * 4 + 1] = sum;
+            }
+            __syncthreads();
+            float* gt = stage;                                    // clipped sampling probabilities [RB][GW] (the stage is free now)
+            if (vmode != 0 && !r.cat_tape) {
+                for (int i = tid; i < RB * gwd; i += K4_THREADS) {
+                    const int row = i / gwd, j = i - row * gwd, col = gs0 + j, bd = min(b0 + row, a.B - 1);
+                    float tt = glog[row * GW + j] / gaux[row * 4 + 1];
+                    if (pull_on && col < a.Dz) tt = (1.0f - r.eta) * tt + r.eta * a.mu[(int64_t)bd * a.ldmu + col];
+                    if (vmode == 2 && clamp) {
+                        const float m = a.mask[(int64_t)bd * a.ldk + col];
+                        tt = tt * (1.0f - m) + a.vk[(int64_t)bd * a.ldk + col] * m;
+                    }
+                    gt[row * GW + j] = fminf(fmaxf(tt, 1e-8f), 1.0f);
+                }
+                __syncthreads();
+            }
+            if (tid < RB) {
+                const int row = tid, bd = min(b0 + row, a.B - 1);
+                int idx = -1;
+                if (vmode != 0) {
+                    if (r.cat_tape) idx = r.cat_tape[bd];
+                    else {       // PHILOX: inverse CDF over the clipped probabilities (oracle/draws.py)
+                        const DrawSrc cs = k4_src(a, r.cat_uni, 1);
+                        const float thr = draw_uniform(cs, bd, 0);
+                        float tot = 0.f;
+                        for (int j = 0; j < gwd; ++j) tot += gt[row * GW + j];
+                        const float target = thr * tot;
+                        float ac = 0.f;
+                        for (int j = 0; j < gwd; ++j) {
+                            ac += gt[row * GW + j];
+                            if (ac > target) { idx = j; break; }
+                        }
+                        if (idx < 0) idx = gwd - 1;
+                    }
+                }
+                gaux[row * 4 + 2] = __int_as_float(idx);
+            }
+            __syncthreads();
+            for (int i = tid; i < RB * gwd; i += K4_THREADS) {
+                const int row = i / gwd, j = i - row * gwd, col = gs0 + j, b = b0 + row, bd = min(b, a.B - 1);
+                float p = glog[row * GW + j] / gaux[row * 4 + 1];
+                if (pull_on && col < a.Dz) p = (1.0f - r.eta) * p + r.eta * a.mu[(int64_t)bd * a.ldmu + col];
+                const float m = clamp ? a.mask[(int64_t)bd * a.ldk + col] : 0.f;
+                const float kn = clamp ? a.vk[(int64_t)bd * a.ldk + col] : 0.f;
+                const int idx = __float_as_int(gaux[row * 4 + 2]);
+                float v;
+                if (vmode == 0) v = clamp ? (p * (1.0f - m) + kn * m) : p;
+                else if (vmode == 1) { const float o = (j == idx) ? 1.f : 0.f; v = clamp ? (o * (1.0f - m) + kn * m) : o; }
+                else v = (j == idx) ? 1.f : 0.f;
+                if (b >= a.B) v = 0.f;
+                k4_put(vact, VK, at, row, col, v, false);
+                if (last && b < a.B) a.state[(int64_t)b * a.lds + col] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace imdbn

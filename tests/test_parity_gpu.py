@@ -116,6 +116,41 @@ def test_philox_chains_and_clamped_match_oracle(B):
         assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
 
 
+@pytest.mark.parametrize("V,H,Dz,B", [(150, 48, 140, 5), (532, 256, 500, 64), (532, 256, 500, 100), (700, 300, 700, 17)])
+def test_row_parallel_chain_kernel_matches_per_launch_path(V, H, Dz, B, _native):
+    """kernels_chain.hpp (one block per 16 batch rows runs the whole chain) against the one-launch-per-half-step
+    path on the same Philox draws: mean-field chains agree to fp32 summation-order noise, and the draw accounting
+    is identical.  (Sampled chains are compared against the oracle in test_philox_chains_and_clamped_match_oracle.)"""
+    from imdbn import engine as E
+    g = np.random.default_rng(11)
+    groups = [(Dz, V)] if Dz < V else None
+    vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+    if groups:
+        vk[:, Dz:] = np.eye(V - Dz, dtype=F32)[np.arange(B) % (V - Dz)]; km[:, Dz:] = 1
+    else:
+        vk[:, :50] = g.random((B, 50), dtype=F32); km[:, :50] = 1
+    mu = g.random((B, min(Dz, V)), dtype=F32)
+    outs = []
+    for no_kernel in (1, 0):
+        _native.set_option("no_chain_kernel", no_kernel)
+        try:
+            r, st, _ = _mk(V, H, groups, seed=3)
+            rng = E.PhiloxRng(seed=9)
+            with E.use_rng(rng):
+                a = r.conditional_gibbs(P.T(vk, DEV), P.T(km, DEV), n_steps=7, sample_h=False, sample_v=False)
+                r._mu_pull = {"mu_k": P.T(mu, DEV), "eta0": 0.15}
+                b = r.noisy_meanfield_annealed(P.T(vk, DEV), P.T(km, DEV), n_steps=33)
+                r._mu_pull = None
+                l = r.train_epoch_clamped(P.T(vk, DEV), P.T(km, DEV), 1, 10, CD=1, cond_init_steps=30, sample_h=False,
+                                          sample_v=False, reclamp_negative=False)
+            outs.append([P.N(a), P.N(b), float(l)] + [P.N(getattr(r, k)) for k in P.KEYS] + [rng.offset])
+        finally:
+            _native.set_option("no_chain_kernel", 0)
+    assert outs[0][-1] == outs[1][-1], "draw accounting differs"
+    for i, (x, w) in enumerate(zip(outs[0][:-1], outs[1][:-1])):
+        assert_close(np.asarray(w), np.asarray(x), 2e-5, f"output {i}", atol=2e-6)
+
+
 @pytest.mark.parametrize("V,H,B", [(150, 48, 5), (532, 256, 64), (1500, 500, 33)])
 def test_free_energy_matches_oracle(V, H, B):
     """imdbn_rbm_free_energy against F(v) = -v.b - sum softplus(c + vW) (energy_utils.py:19-28); both K1 forms

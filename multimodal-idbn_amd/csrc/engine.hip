@@ -30,7 +30,7 @@ int g_k4_rows = 0;          // tuning: batch rows per chain-kernel block (0 = au
 int g_no_chain_kernel = 0;  // testing: run chains as one launch per half step
 int g_no_bits = 0;  // testing: never use the bit-packed hidden operand
 int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
-int g_dbg = 0;    // tuning/testing: force the generic K3
+int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;

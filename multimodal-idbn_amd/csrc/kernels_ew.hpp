@@ -135,7 +135,7 @@ struct FinishArgs {
     float* colsum_part; int colsum_src;            // [Bp/32][N]
     const float* loss_ref; int64_t ld_ref; int loss_src; float* loss_part;   // one per block (+ one per group)
     int simple;                                    // set by the host: none of T / noise / mu / clamp / groups / logits_only in use
-    int dbg;                                       // timing experiments only: 1 = skip epilogue, 2 = skip GEMM loop
+    int dbg;                                       // tuning aid: which kernels record per-block timeline stamps (common.hpp stamp)
 };
 
 // gs / ge are only ever indexed with compile-time constants: a dynamically indexed member pins the whole struct in

@@ -259,8 +259,7 @@ __device__ __forceinline__ void up4_body(const float* __restrict__ W, int64_t ld
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             __builtin_amdgcn_sched_barrier(0);
-            if (kb + 64 * d < k_end && !(dbg & 1)) compute(ring[d]);      // wave-uniform
-            else if (dbg & 1) acc[0][0][0] += ring[d].wv[0].x + __uint_as_float(ring[d].av[0][0].x);
+            if (kb + 64 * d < k_end) compute(ring[d]);                    // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
             if (kb == kb0 && d == 0) stamp(st, sblk, 2);
             load(ring[d], kb + 64 * (d + D));                             // refill D blocks ahead
@@ -270,7 +269,6 @@ __device__ __forceinline__ void up4_body(const float* __restrict__ W, int64_t ld
     // cross-wave reduction (fixed order) and float4 slab stores: thread -> 4 interleaved columns of one row
     float* slab = partial + (int64_t)ks * Bp * N;
     const bool cok = (n0 + 4 * r) < N;
-    if (dbg & 2) { if (acc[0][0][0] == 123.456f) slab[0] = 1.f; return; }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         __syncthreads();
@@ -381,7 +379,6 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
         } else {
 #pragma unroll
             for (int ta = 0; ta < NA; ++ta) {
-                if (fa.dbg & 8) { o.av[ta][0] = make_uint4(kb, 0, 0, 0); o.av[ta][1] = make_uint4(0, kb, 0, 0); continue; }
                 o.av[ta][0] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow0) * 16 + 8 * hh);
                 o.av[ta][1] = *reinterpret_cast<const uint4*>(A + ta * a_term_stride + (ablk + arow1) * 16 + 8 * hh);
             }
@@ -422,12 +419,11 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     load_side<8>(fa, (tid & 31) < TR ? n0 + (tid & 31) : (1 << 30), mb + (tid >> 5) * 8, side);
 #pragma unroll
     for (int d = 0; d < D; ++d) load(ring[d], 16 * (w * D + d));
-    for (int g = 0; (4 * g + w) * D < ((fa.dbg & 2) ? 0 : nblk); ++g) {
+    for (int g = 0; (4 * g + w) * D < nblk; ++g) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             __builtin_amdgcn_sched_barrier(0);
-            if (!BITS && (fa.dbg & 4)) acc[0][0] += ring[d].wv[0] + ring[d].wv[7] + __uint_as_float(ring[d].av[0][0].x) + __uint_as_float(ring[d].av[0][1].w);
-            else if ((4 * g + w) * D + d < nblk) compute(ring[d]);             // wave-uniform
+            if ((4 * g + w) * D + d < nblk) compute(ring[d]);             // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
             load(ring[d], 16 * ((4 * (g + 1) + w) * D + d));              // refill the slot for the next group
         }
@@ -460,8 +456,7 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     // the reduction buffer is free again: it stages the K16-blocked operand tile [term][2 column groups][64 rows][16]
     const bool staged = fa.rm_src && !fa.logits_only && TR == 32;      // needs 16-column-aligned tiles
     const RmStage stg{reinterpret_cast<bf16_t*>(red), 2, 64, n0, mb};
-    if (!(fa.dbg & 1)) lsum = finish_rows8(fa, ecol, mb + oct * 8, xs, (mb >> 3) + oct, side, staged ? &stg : nullptr);
-    else if (xs[0] == 123.456f) fa.out_prob[0] = xs[1];
+    lsum = finish_rows8(fa, ecol, mb + oct * 8, xs, (mb >> 3) + oct, side, staged ? &stg : nullptr);
     stamp(st, sblk, 5);
     if (staged) {
         __syncthreads();

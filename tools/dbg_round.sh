@@ -1,5 +1,6 @@
 #!/bin/bash
-# timing experiments: kernel stats of bench.py under different engine options
+# kernel stats of bench.py under different engine options (imdbn_set_option name=value, comma separated), e.g.
+#   bash tools/dbg_round.sh down_rows=32 no_bits=1 ksplit_up=10
 set -o pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }

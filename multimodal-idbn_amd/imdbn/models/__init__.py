@@ -5,9 +5,10 @@ from types import ModuleType
 from .rbm import RBM
 from .idbn import iDBN
 from .imdbn import iMDBN
+from .imdbn_bimodal import iMDBN_BiModal
 from . import gdbn_model_complete  # noqa: F401  (monolith path used by reference-written pickles)
 
-__all__ = ["RBM", "iDBN", "iMDBN"]
+__all__ = ["RBM", "iDBN", "iMDBN", "iMDBN_BiModal"]
 
 # Legacy Groundeep pickles name their classes src.classes.{rbm_model,dbn_model,gdbn_model}.*
 _this = sys.modules[__name__]

@@ -559,6 +559,91 @@ def train_joint_batch(img_layers, joint: RBMState, img, y, epoch: int, b_idx: in
 # ---------------------------------------------------------------------------
 # free energy (imdbn/utils/energy_utils.py:19-28) -- spec for the opt-in live best-of-K
 # ---------------------------------------------------------------------------
+# ---- iMDBN_BiModal (imdbn_bimodal.py) ------------------------------------------------------------
+def bimodal_init_joint_bias(mod1_layers, mod2_layers, joint0: RBMState, batches, n_batches: int = 10):
+    """imdbn_bimodal.py:617-645: logit of the clamped mean latent of each modality -> first joint layer's vis_bias."""
+    s1 = s2 = None
+    n = 0
+    for b, (m1, m2) in enumerate(batches):
+        if b >= n_batches:
+            break
+        z1 = idbn_represent(mod1_layers, np.asarray(m1, F32).reshape(len(m1), -1))
+        z2 = idbn_represent(mod2_layers, np.asarray(m2, F32).reshape(len(m2), -1))
+        s1 = z1.sum(0, dtype=F32) if s1 is None else (s1 + z1.sum(0, dtype=F32)).astype(F32)
+        s2 = z2.sum(0, dtype=F32) if s2 is None else (s2 + z2.sum(0, dtype=F32)).astype(F32)
+        n += z1.shape[0]
+    if n == 0:
+        return
+    Dz1 = s1.shape[0]
+    m1 = np.clip((s1 / F32(n)).astype(F32), F32(1e-4), F32(1 - 1e-4)).astype(F32)
+    m2 = np.clip((s2 / F32(n)).astype(F32), F32(1e-4), F32(1 - 1e-4)).astype(F32)
+    joint0.vis_bias[:Dz1] = (np.log(m1) - np.log1p(-m1)).astype(F32)
+    joint0.vis_bias[Dz1:] = (np.log(m2) - np.log1p(-m2)).astype(F32)
+
+
+def bimodal_cross_reconstruct(mod1_layers, mod2_layers, joint0: RBMState, z1, z2, steps: int, rng):
+    """imdbn_bimodal.py:648-693: Gibbs completion (sampled hidden units) in both directions, then decode."""
+    z1 = np.asarray(z1, F32); z2 = np.asarray(z2, F32)
+    B, Dz1 = z1.shape
+    V = Dz1 + z2.shape[1]
+    vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+    vk[:, :Dz1] = z1; km[:, :Dz1] = 1.0
+    v12 = conditional_gibbs(joint0, vk, km, rng, n_steps=steps, sample_h=True, sample_v=False)
+    vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+    vk[:, Dz1:] = z2; km[:, Dz1:] = 1.0
+    v21 = conditional_gibbs(joint0, vk, km, rng, n_steps=steps, sample_h=True, sample_v=False)
+    return idbn_decode(mod1_layers, v21[:, :Dz1]), idbn_decode(mod2_layers, v12[:, Dz1:])
+
+
+def bimodal_represent(mod1_layers, mod2_layers, joint_layers, m1, m2):
+    """imdbn_bimodal.py:696-709."""
+    h = np.concatenate([idbn_represent(mod1_layers, np.asarray(m1, F32).reshape(len(m1), -1)),
+                        idbn_represent(mod2_layers, np.asarray(m2, F32).reshape(len(m2), -1))], axis=1)
+    for st in joint_layers:
+        h = forward(st, h)
+    return h
+
+
+def bimodal_train_joint_batch(mod1_layers, mod2_layers, joint_layers, m1, m2, epoch: int, rng, joint_cd: int,
+                              aux_cond_steps: int, cross_steps: int, warmup_epochs: int = 8):
+    """One iteration of the batch loop imdbn_bimodal.py:741-829; returns the online metric terms."""
+    v1 = np.asarray(m1, F32).reshape(len(m1), -1)
+    v2 = np.asarray(m2, F32).reshape(len(m2), -1)
+    z1 = idbn_represent(mod1_layers, v1)
+    z2 = idbn_represent(mod2_layers, v2)
+    B, Dz1 = z1.shape
+    V = Dz1 + z2.shape[1]
+    first = joint_layers[0]
+    loss_cd = None
+
+    def clamp(z, lo):
+        vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+        vk[:, lo:lo + z.shape[1]] = z; km[:, lo:lo + z.shape[1]] = 1.0
+        return vk, km
+
+    if epoch < warmup_epochs:                                                 # :750-781
+        for _ in range(2):
+            for z, lo in ((z1, 0), (z2, Dz1)):
+                vk, km = clamp(z, lo)
+                train_epoch_clamped(first, vk, km, epoch, rng, CD=3, cond_init_steps=aux_cond_steps,
+                                    sample_h=True, sample_v=False, aux_lr_mult=0.3, use_noisy_init=True)
+    else:                                                                     # :783-820
+        cur = np.concatenate([z1, z2], axis=1)
+        for li, st in enumerate(joint_layers):
+            loss = train_epoch(st, cur, epoch, joint_cd, rng)
+            if li == 0:
+                loss_cd = loss
+            cur = forward(st, cur)
+        for z, lo in ((z1, 0), (z2, Dz1)):
+            vk, km = clamp(z, lo)
+            train_epoch_clamped(first, vk, km, epoch, rng, CD=3, cond_init_steps=aux_cond_steps,
+                                sample_h=True, sample_v=False, reclamp_negative=False, aux_lr_mult=0.3,
+                                use_noisy_init=True)
+    r1, r2 = bimodal_cross_reconstruct(mod1_layers, mod2_layers, first, z1, z2, cross_steps, rng)
+    return dict(loss_cd=loss_cd, n=B, mse1_sum=float(F32(((r1 - v1) ** 2).sum(dtype=F32))),
+                mse2_sum=float(F32(((r2 - v2) ** 2).sum(dtype=F32))), mod1_from_mod2=r1, mod2_from_mod1=r2)
+
+
 def free_energy(st: RBMState, v: np.ndarray) -> np.ndarray:
     v = np.asarray(v, F32)
     wx_b = (v @ st.W) + st.hid_bias

@@ -400,6 +400,72 @@ def case_imdbn_small():
          yi=yi.astype(np.int32), cd_losses=np.array(cd_losses, np.float32), **out)
 
 
+def case_bimodal_small(seed=None, write=True):
+    """iMDBN_BiModal (imdbn_bimodal.py): two modality stacks, a two-layer joint DBN, warm-up + main phase.
+    seed=None: the seed (of 505..540) whose closest Bernoulli decision |p-u| is widest."""
+    from imdbn.models.imdbn_bimodal import iMDBN_BiModal
+    if seed is None:
+        seed = max(range(505, 541), key=lambda sd: case_bimodal_small(sd, write=False))
+    s = DrawStream(seed)
+    s1, s2, joint = [100, 40, 20], [64, 30, 16], [24, 12]
+    B, NB, K = 8, 4, 5
+    N = B * NB
+    yi = (np.arange(N) * 3 + (np.arange(N) // 5)) % K
+    X1 = np.abs((s.uniform((K, 100)) > 0.7).astype(np.float32)[yi] - (s.uniform((N, 100)) > 0.9).astype(np.float32)).astype(np.float32)
+    X2 = np.abs((s.uniform((K, 64)) > 0.6).astype(np.float32)[yi] - (s.uniform((N, 64)) > 0.92).astype(np.float32)).astype(np.float32)
+    dl = _loader(X1, X2, B)
+    params = dict(PARAMS, JOINT_LEARNING_RATE=0.05, JOINT_CD=1, CROSS_GIBBS_STEPS=5, JOINT_AUX_COND_STEPS=7)
+    m = iMDBN_BiModal(s1, s2, joint, params=params, dataloader=dl, val_loader=dl, device=torch.device("cpu"))
+    with torch.no_grad():
+        for sizes, dbn in ((s1, m.mod1_dbn), (s2, m.mod2_dbn)):
+            for i, r in enumerate(dbn.layers):
+                r.W.copy_(torch.from_numpy(init_W(s, sizes[i], sizes[i + 1])))
+        vis = s1[-1] + s2[-1]
+        for r, h in zip(m.joint_layers, joint):
+            r.W.copy_(torch.from_numpy(init_W(s, vis, h)))
+            vis = h
+    cd_losses, cross = [], []
+    first = m.joint_layers[0]
+    o_te, o_cr = first.train_epoch, m._cross_reconstruct
+    first.train_epoch = lambda *a, **k: (lambda L: (cd_losses.append(float(L)), L)[1])(o_te(*a, **k))
+
+    def cr(*a, **k):
+        r_ = o_cr(*a, **k)
+        cross.append((r_[0].numpy().copy(), r_[1].numpy().copy()))
+        return r_
+
+    m._cross_reconstruct = cr
+    out = {}
+    with Substitute(s) as sub:
+        sub._vshape = s1[-1] + s2[-1]
+        m.train_joint(10)            # epochs 0-7 warm-up, 8-9 main phase
+    del first.train_epoch, m._cross_reconstruct
+    if not write:
+        return sub.min_margin
+    for li, r in enumerate(m.joint_layers):
+        for k, v in state_of(r).items():
+            out[f"joint{li}_{k}"] = v
+    for e in (0, 7, 8, 9):
+        out[f"cross_m1_e{e}_last"] = cross[e * NB + NB - 1][0]
+        out[f"cross_m2_e{e}_last"] = cross[e * NB + NB - 1][1]
+    out["cross_m1_sum_per_epoch"] = np.array([sum(float(c[0].astype(np.float64).sum()) for c in cross[e * NB:(e + 1) * NB]) for e in range(10)])
+    out["cross_m2_sum_per_epoch"] = np.array([sum(float(c[1].astype(np.float64).sum()) for c in cross[e * NB:(e + 1) * NB]) for e in range(10)])
+    with torch.no_grad():
+        out["represent"] = m.represent((torch.from_numpy(X1[:8]), torch.from_numpy(X2[:8]))).numpy()
+    with Substitute(s):
+        z1 = m.mod1_dbn.represent(torch.from_numpy(X1[:8]))
+        z2 = m.mod2_dbn.represent(torch.from_numpy(X2[:8]))
+        a, b = m._cross_reconstruct(z1, z2, steps=9)
+        out["xr_m1"], out["xr_m2"] = a.numpy(), b.numpy()
+    m.save_model(os.path.join(HERE, "ref_bimodal_small.pkl"))
+    save("bimodal_small_100_40_20__64_30_16__j24_12.npz",
+         dict(seed=seed, sizes1=s1, sizes2=s2, joint=joint, K=K, B=B, NB=NB, params=params, joint_epochs=10,
+              min_margin=sub.min_margin, draw_log_len=len(s.log), _cat=s.cat_record,
+              recipe="s=DrawStream(seed); X1=|(s.uniform(K,100)>.7)[yi]-(s.uniform(N,100)>.9)|; X2=|(s.uniform(K,64)>.6)[yi]-"
+                     "(s.uniform(N,64)>.92)|; W init per mod1 layer, mod2 layer, joint layer; train_joint(10); _cross_reconstruct(steps=9)"),
+         yi=yi.astype(np.int32), cd_losses=np.array(cd_losses, np.float32), **out)
+
+
 # ---------------------------------------------------------------------------
 # C2 digest: the headline RBM 10000<->1500, batch 64, CD-1, 3 updates (weights too big to ship)
 # ---------------------------------------------------------------------------
@@ -427,9 +493,10 @@ def case_c2_digest():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c1", "joint", "idbn", "imdbn", "c2"]
+    which = sys.argv[1:] or ["c1", "joint", "idbn", "imdbn", "bimodal", "c2"]
     if "c1" in which: case_c1()
     if "joint" in which: case_joint_small()
     if "idbn" in which: case_idbn_small()
     if "imdbn" in which: case_imdbn_small()
+    if "bimodal" in which: case_bimodal_small()
     if "c2" in which: case_c2_digest()

@@ -13,7 +13,7 @@ from torch.utils.data import DataLoader, TensorDataset
 
 from golden_utils import Fixture, assert_close, init_W
 from imdbn import engine as E
-from imdbn.models import RBM, iDBN, iMDBN
+from imdbn.models import RBM, iDBN, iMDBN, iMDBN_BiModal
 
 F32 = np.float32
 KEYS = ("W", "hid_bias", "vis_bias", "W_m", "hb_m", "vb_m")
@@ -286,3 +286,60 @@ def case_live_best_of_k(dev, V=150, H=48, Dz=140, B=9, K=7, rel=1e-4):
     np.testing.assert_array_equal(pick, cands[best, np.arange(B)])
     # the refinement is a deterministic mean-field step: candidate k+1 = one clamped down(up(.)) pass at T = 0.9
     return en
+
+
+def case_bimodal_small(dev, rel=3e-4):
+    """iMDBN_BiModal through the product classes against the fixture generated from the reference class
+    (warm-up epochs 0-7: clamped CD-3 with sampled hidden units; epochs 8-9: two-layer joint CD + clamped CD-3;
+    bidirectional Gibbs cross reconstruction on every batch)."""
+    fx = Fixture("bimodal_small_100_40_20__64_30_16__j24_12.npz")
+    m = fx.meta
+    s = fx.stream()
+    K, B, NB = m["K"], m["B"], m["NB"]
+    Nn = B * NB
+    yi = fx["yi"]
+    X1 = np.abs((s.uniform((K, 100)) > 0.7).astype(F32)[yi] - (s.uniform((Nn, 100)) > 0.9).astype(F32)).astype(F32)
+    X2 = np.abs((s.uniform((K, 64)) > 0.6).astype(F32)[yi] - (s.uniform((Nn, 64)) > 0.92).astype(F32)).astype(F32)
+    dl = loader(X1, X2, B)
+    mdl = iMDBN_BiModal(m["sizes1"], m["sizes2"], m["joint"], params=dict(m["params"]), dataloader=dl, val_loader=dl,
+                        device=torch.device(dev))
+    for sizes, dbn in ((m["sizes1"], mdl.mod1_dbn), (m["sizes2"], mdl.mod2_dbn)):
+        for i, r in enumerate(dbn.layers):
+            set_params(r, dev, init_W(s, sizes[i], sizes[i + 1]))
+    vis = m["sizes1"][-1] + m["sizes2"][-1]
+    for r, h in zip(mdl.joint_layers, m["joint"]):
+        set_params(r, dev, init_W(s, vis, h))
+        vis = h
+    cross = []
+    orig = mdl._cross_reconstruct
+
+    def rec(*a, **k):
+        out = orig(*a, **k)
+        cross.append((N(out[0]), N(out[1])))
+        return out
+
+    mdl._cross_reconstruct = rec
+    with E.use_rng(E.ReplayRng(s)):
+        mdl.train_joint(m["joint_epochs"])
+        del mdl._cross_reconstruct
+        for li, r in enumerate(mdl.joint_layers):
+            check_state(r, fx, f"joint{li}_", rel)
+        cd = torch.cat([h["cd_losses"] for h in mdl.joint_history if h["cd_losses"] is not None]).numpy()
+        assert_close(cd, fx["cd_losses"], 2e-4, "cd losses")
+        for e in (0, 7, 8, 9):
+            assert_close(cross[e * NB + NB - 1][0], fx[f"cross_m1_e{e}_last"], rel, f"mod1<-mod2 epoch {e}")
+            assert_close(cross[e * NB + NB - 1][1], fx[f"cross_m2_e{e}_last"], rel, f"mod2<-mod1 epoch {e}")
+        s1 = np.array([sum(float(c[0].astype(np.float64).sum()) for c in cross[e * NB:(e + 1) * NB]) for e in range(10)])
+        s2 = np.array([sum(float(c[1].astype(np.float64).sum()) for c in cross[e * NB:(e + 1) * NB]) for e in range(10)])
+        assert_close(s1, fx["cross_m1_sum_per_epoch"], 2e-4, "sum mod1 per epoch")
+        assert_close(s2, fx["cross_m2_sum_per_epoch"], 2e-4, "sum mod2 per epoch")
+        assert_close(N(mdl.represent((torch.from_numpy(X1[:8]), torch.from_numpy(X2[:8])))), fx["represent"], 2e-4,
+                     "iMDBN_BiModal.represent")
+        z1 = mdl.mod1_dbn.represent(torch.from_numpy(X1[:8]))
+        z2 = mdl.mod2_dbn.represent(torch.from_numpy(X2[:8]))
+        a, b = mdl._cross_reconstruct(z1, z2, steps=9)
+        assert_close(N(a), fx["xr_m1"], rel, "xr mod1"); assert_close(N(b), fx["xr_m2"], rel, "xr mod2")
+    # the online metric of the last epoch is the mean squared error over the epoch's batches
+    h = mdl.joint_history[-1]
+    assert h["mod1_mse"] is not None and 0.0 < h["mod1_mse"] < 1.0 and 0.0 < h["mod2_mse"] < 1.0
+    return mdl

@@ -32,6 +32,21 @@ def test_imdbn_small_host_logic():
     P.case_imdbn_small("cpu", rel=2e-4)
 
 
+def test_bimodal_small_host_logic(tmp_path):
+    mdl = P.case_bimodal_small("cpu", rel=3e-4)
+    # pickle round trip in the reference's format, and a reference-written pickle loads into these classes
+    path = str(tmp_path / "bimodal.pkl")
+    mdl.save_model(path)
+    from imdbn.models import iMDBN_BiModal
+    pl = iMDBN_BiModal.load_model(path, device=torch.device("cpu"))
+    assert pl["num_joint_layers"] == 2 and pl["metadata"]["model_type"] == "iMDBN_BiModal"
+    import os
+    ref = iMDBN_BiModal.load_model(os.path.join(os.path.dirname(__file__), "golden", "ref_bimodal_small.pkl"), device=torch.device("cpu"))
+    assert [tuple(r.W.shape) for r in ref["joint_layers"]] == [(36, 24), (24, 12)]
+    for a, b in zip(ref["joint_layers"], mdl.joint_layers):
+        assert torch.allclose(a.W.cpu(), b.W.detach().cpu(), rtol=0, atol=3e-4)
+
+
 def test_live_best_of_k_host_logic():
     P.case_live_best_of_k("cpu")
 

@@ -216,6 +216,62 @@ def test_imdbn_small_train_joint_and_cross_reconstruct():
     assert s.exhausted_cat()
 
 
+def _bimodal_inputs(fx):
+    m = fx.meta
+    s = fx.stream()
+    K, B, NB = m["K"], m["B"], m["NB"]
+    N = B * NB
+    yi = fx["yi"]
+    X1 = np.abs((s.uniform((K, 100)) > 0.7).astype(F32)[yi] - (s.uniform((N, 100)) > 0.9).astype(F32)).astype(F32)
+    X2 = np.abs((s.uniform((K, 64)) > 0.6).astype(F32)[yi] - (s.uniform((N, 64)) > 0.92).astype(F32)).astype(F32)
+    return s, X1, X2
+
+
+def test_bimodal_small_train_joint_and_cross_reconstruct():
+    """iMDBN_BiModal (imdbn_bimodal.py:617-829): warm-up + main phase on a two-layer joint DBN."""
+    fx = Fixture("bimodal_small_100_40_20__64_30_16__j24_12.npz")
+    m = fx.meta
+    s, X1, X2 = _bimodal_inputs(fx)
+    p = m["params"]
+    B, NB = m["B"], m["NB"]
+
+    def stack(sizes):
+        return [O.RBMState.create(init_W(s, sizes[i], sizes[i + 1]), p["LEARNING_RATE"], p["WEIGHT_PENALTY"], p["INIT_MOMENTUM"],
+                                  dynamic_lr=True, final_momentum=p["FINAL_MOMENTUM"],
+                                  sparsity=(p["SPARSITY"] and i == len(sizes) - 2), sparsity_factor=p["SPARSITY_FACTOR"])
+                for i in range(len(sizes) - 1)]
+
+    l1, l2 = stack(m["sizes1"]), stack(m["sizes2"])
+    joint, vis = [], m["sizes1"][-1] + m["sizes2"][-1]
+    for h in m["joint"]:
+        joint.append(O.RBMState.create(init_W(s, vis, h), p["JOINT_LEARNING_RATE"], p["WEIGHT_PENALTY"], p["INIT_MOMENTUM"],
+                                       dynamic_lr=True, final_momentum=p["FINAL_MOMENTUM"]))
+        vis = h
+    batches = [(X1[b * B:(b + 1) * B], X2[b * B:(b + 1) * B]) for b in range(NB)]
+    O.bimodal_init_joint_bias(l1, l2, joint[0], batches, n_batches=10)
+    cd_losses, s1, s2 = [], [], []
+    for epoch in range(m["joint_epochs"]):
+        a1 = a2 = 0.0
+        for b_idx, (m1, m2) in enumerate(batches):
+            r = O.bimodal_train_joint_batch(l1, l2, joint, m1, m2, epoch, s, p["JOINT_CD"], p["JOINT_AUX_COND_STEPS"],
+                                            p["CROSS_GIBBS_STEPS"])
+            if r["loss_cd"] is not None:
+                cd_losses.append(r["loss_cd"])
+            a1 += float(r["mod1_from_mod2"].astype(np.float64).sum()); a2 += float(r["mod2_from_mod1"].astype(np.float64).sum())
+            if b_idx == NB - 1 and epoch in (0, 7, 8, 9):
+                assert_close(r["mod1_from_mod2"], fx[f"cross_m1_e{epoch}_last"], 2e-4, f"mod1<-mod2 epoch {epoch}")
+                assert_close(r["mod2_from_mod1"], fx[f"cross_m2_e{epoch}_last"], 2e-4, f"mod2<-mod1 epoch {epoch}")
+        s1.append(a1); s2.append(a2)
+    assert_close(np.array(cd_losses, F32), fx["cd_losses"], 1e-4, "cd losses")
+    assert_close(np.array(s1), fx["cross_m1_sum_per_epoch"], 1e-4, "sum mod1 per epoch")
+    assert_close(np.array(s2), fx["cross_m2_sum_per_epoch"], 1e-4, "sum mod2 per epoch")
+    for li, st in enumerate(joint):
+        _check_state(st, fx, f"joint{li}_", rel=2e-4)
+    assert_close(O.bimodal_represent(l1, l2, joint, X1[:8], X2[:8]), fx["represent"], 1e-4, "iMDBN_BiModal.represent")
+    a, b = O.bimodal_cross_reconstruct(l1, l2, joint[0], O.idbn_represent(l1, X1[:8]), O.idbn_represent(l2, X2[:8]), 9, s)
+    assert_close(a, fx["xr_m1"], 2e-4, "xr mod1"); assert_close(b, fx["xr_m2"], 2e-4, "xr mod2")
+
+
 @pytest.mark.slow
 def test_c2_headline_digest():
     """10000<->1500, batch 64, 3 updates: digests only (the weights are 60 MB)."""

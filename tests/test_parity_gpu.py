@@ -42,6 +42,10 @@ def test_idbn_small_fixture_gpu():
     P.case_idbn_small(DEV, rel=1e-4)
 
 
+def test_bimodal_small_fixture_gpu():
+    P.case_bimodal_small(DEV, rel=3e-4)
+
+
 def test_imdbn_small_fixture_gpu():
     P.case_imdbn_small(DEV, rel=3e-4)
 

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     ap.add_argument("--force-dp", action="store_true", help="take the stats/all-reduce/apply path even with one rank")
     ap.add_argument("--no-k3-events", action="store_true", help="do not bracket K3 with HIP events in the timed region")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank flow on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -109,12 +110,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.backend != "nccl":
+        local = local % torch.cuda.device_count()          # rehearsal: several ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:

@@ -412,7 +412,7 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
     const bool prof = g_prof.on && !mode_stats && (g_prof.calls++ % 4 == 0) && g_prof.used + 2 <= g_prof.ev.size();
     if (prof) HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], c.s));
     // fast path: every W / W_m / delta row start 16-B aligned -> float4 weight tiles, LDS-staged planes
-    const bool fast = L.Bp == 64 && L.H % 4 == 0 && L.H >= 4 && c.d->ldw % 4 == 0 && (((uintptr_t)c.d->W) & 15) == 0 &&
+    const bool fast = L.H % 4 == 0 && L.H >= 4 && c.d->ldw % 4 == 0 && (((uintptr_t)c.d->W) & 15) == 0 &&
                       (mode_stats ? ((((uintptr_t)delta) & 15) == 0) : ((((uintptr_t)c.d->W_m) & 15) == 0)) && !g_no_fast_k3;
     if (fast) {
         AssocPlanesArgs f;
@@ -432,11 +432,18 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
         BiasArgs bz;
         memset(&bz, 0, sizeof(bz));
         const BiasArgs& bb = bias ? *bias : bz;
-        dim3 g(nh, cdiv(nv, tpb) + brows);
-#define LAUNCH_K3(M, HTV) hipLaunchKernelGGL((assoc_update_planes<M, HTV>), g, dim3(256), 0, c.s, f, tpb, bb, brows)
-        if (c.rt == 3) { if (mode_stats) LAUNCH_K3(1, 3); else LAUNCH_K3(0, 3); }
-        else           { if (mode_stats) LAUNCH_K3(1, 1); else LAUNCH_K3(0, 1); }
+        // one launch per 64-row batch chunk (kernels_gemm.hpp AssocPlanesArgs::pass); the bias / loss blocks ride on the last
+        const int nchunk = L.Bp / 64;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            f.b0 = 64 * ch;
+            f.pass = nchunk == 1 ? 0 : (ch == 0 ? 1 : (ch == nchunk - 1 ? 3 : 2));
+            const int br = (ch == nchunk - 1) ? brows : 0;
+            dim3 g(nh, cdiv(nv, tpb) + br);
+#define LAUNCH_K3(M, HTV) hipLaunchKernelGGL((assoc_update_planes<M, HTV>), g, dim3(256), 0, c.s, f, tpb, bb, br)
+            if (c.rt == 3) { if (mode_stats) LAUNCH_K3(1, 3); else LAUNCH_K3(0, 3); }
+            else           { if (mode_stats) LAUNCH_K3(1, 1); else LAUNCH_K3(0, 1); }
 #undef LAUNCH_K3
+        }
         HIPCHK(hipGetLastError());
         if (prof) { HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], c.s)); g_prof.used += 2; }
         return 0;

@@ -526,6 +526,13 @@ struct AssocArgs {
     float lr, mom, wd, n;
     float* delta;
     int dbg;
+    // batches of more than one 64-row chunk: one launch per chunk, b0 = first batch row of this launch's chunk and
+    // pass = 0 single chunk | 1 first | 2 middle | 3 last.  The momentum update is linear in the statistics:
+    //   first : W_m <- mom*W_m + lr*(d/n - wd*W)        (W untouched)
+    //   middle: W_m <- W_m + lr*d/n
+    //   last  : W_m <- W_m + lr*d/n ;  W <- W + W_m
+    // (statistics mode: first writes delta, the others add to it)
+    int b0, pass;
 };
 
 // All operand fragments of one 16-row batch block for this wave's 32(v) x 64(h) tile.
@@ -695,6 +702,13 @@ struct AssocPlanesArgs {
     float lr, mom, wd, n;
     float* delta;
     int dbg;
+    // batches of more than one 64-row chunk: one launch per chunk, b0 = first batch row of this launch's chunk and
+    // pass = 0 single chunk | 1 first | 2 middle | 3 last.  The momentum update is linear in the statistics:
+    //   first : W_m <- mom*W_m + lr*(d/n - wd*W)        (W untouched)
+    //   middle: W_m <- W_m + lr*d/n
+    //   last  : W_m <- W_m + lr*d/n ;  W <- W + W_m
+    // (statistics mode: first writes delta, the others add to it)
+    int b0, pass;
 };
 
 __device__ __forceinline__ int k3_swz(int row, int c) { return row * K3_ROWB + ((c ^ ((row >> 1) & 7)) << 4); }
@@ -766,7 +780,8 @@ __device__ __forceinline__ void k3_mfma_wave(f32x16 (&acc)[4], const char* sH, c
 // tile collapses onto one row, unused slices are still loaded (clamped plane index, L2 hits).
 // After the hidden staging there is no block barrier: the four waves run independently and drift apart, which
 // smooths the load / store bursts.  One wave per SIMD (two 128-register weight tiles in flight).
-// Requires Bp == 64 (one batch chunk) and 16-B aligned weight rows; otherwise the generic kernel runs.
+// One launch handles ONE 64-row batch chunk (a.b0); larger batches take one launch per chunk (a.pass).
+// Requires 16-B aligned weight rows; otherwise the generic kernel runs.
 template <int MODE, int HT>
 __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, int bx, int by, int tiles_per_block,
                                         int nap, int nan_) {
@@ -786,14 +801,23 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
     char* sV = smem + K3_VIS0 + w * (4 * K3_SLICE);                    // this wave's four slices
     const uint32_t sV_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sV);
 
+    const float* Wsrc = (a.pass == 2) ? a.Wm : a.W;            // middle passes do not need W: repeat the W_m address (same lines)
     auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0, bool valid) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = valid ? min(v0 + 32 * w + mfma_row(reg, l), a.V - 1) : tile0 * 128;
                 const int64_t idx = (int64_t)row * a.ldw + colc;
-                wo[reg] = *reinterpret_cast<const float4*>(a.W + idx);
+                wo[reg] = *reinterpret_cast<const float4*>(Wsrc + idx);
                 mo[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
+            }
+        } else {
+            if (a.pass >= 2) {                                   // statistics of a later batch chunk: add to delta
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = valid ? min(v0 + 32 * w + mfma_row(reg, l), a.V - 1) : tile0 * 128;
+                    mo[reg] = *reinterpret_cast<const float4*>(a.delta + (int64_t)row * a.H + colc);
+                }
             }
         }
     };
@@ -804,7 +828,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = l + 64 * q, row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);      // source chunk for LDS position i
-            k3_dma16(src + (int64_t)min(v0w + row, a.V - 1) * a.Bp + 8 * c, sV_lds + slot * K3_SLICE + q * 1024);
+            k3_dma16(src + (int64_t)min(v0w + row, a.V - 1) * a.Bp + a.b0 + 8 * c, sV_lds + slot * K3_SLICE + q * 1024);
         }
     };
 
@@ -826,7 +850,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = 4 * w + jj, i = 64 * j + l, lrow = i >> 3, pos = i & 7;
                 const int row = 4 * (lrow & 31) + (lrow >> 5), c = pos ^ ((lrow >> 1) & 7);
-                const bf16_t* src = (ph ? a.hneg : a.hpos) + tb * a.hts + (int64_t)min(h0 + row, a.H - 1) * a.Bp + 8 * c;
+                const bf16_t* src = (ph ? a.hneg : a.hpos) + tb * a.hts + (int64_t)min(h0 + row, a.H - 1) * a.Bp + a.b0 + 8 * c;
                 k3_dma16(src, sH_lds + (3 * ph + tb) * K3_PLANE + j * 1024);
             }
     __builtin_amdgcn_sched_barrier(0);
@@ -880,14 +904,21 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
                         float4 m = mc[reg];
                         const float gx = POW2 ? d.x * inv_n : d.x / a.n, gy = POW2 ? d.y * inv_n : d.y / a.n;
                         const float gz = POW2 ? d.z * inv_n : d.z / a.n, gw = POW2 ? d.w * inv_n : d.w / a.n;
-                        m.x = m.x * a.mom; m.x = m.x + a.lr * (gx - a.wd * w0.x);        // rbm.py:212
-                        m.y = m.y * a.mom; m.y = m.y + a.lr * (gy - a.wd * w0.y);
-                        m.z = m.z * a.mom; m.z = m.z + a.lr * (gz - a.wd * w0.z);
-                        m.w = m.w * a.mom; m.w = m.w + a.lr * (gw - a.wd * w0.w);
+                        if (a.pass <= 1) {                                               // single chunk, or the first of several
+                            m.x = m.x * a.mom; m.x = m.x + a.lr * (gx - a.wd * w0.x);        // rbm.py:212
+                            m.y = m.y * a.mom; m.y = m.y + a.lr * (gy - a.wd * w0.y);
+                            m.z = m.z * a.mom; m.z = m.z + a.lr * (gz - a.wd * w0.z);
+                            m.w = m.w * a.mom; m.w = m.w + a.lr * (gw - a.wd * w0.w);
+                        } else {                                                         // later chunks: the statistics term only
+                            m.x = m.x + a.lr * gx; m.y = m.y + a.lr * gy; m.z = m.z + a.lr * gz; m.w = m.w + a.lr * gw;
+                        }
                         *reinterpret_cast<float4*>(a.Wm + idx) = m;
-                        *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
+                        if (a.pass == 0 || a.pass == 3)
+                            *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
                     } else {
-                        *reinterpret_cast<float4*>(a.delta + (int64_t)row * a.H + h0 + 4 * r) = d;
+                        float4 o = d;
+                        if (a.pass >= 2) { const float4 p = mc[reg]; o = make_float4(p.x + d.x, p.y + d.y, p.z + d.z, p.w + d.w); }
+                        *reinterpret_cast<float4*>(a.delta + (int64_t)row * a.H + h0 + 4 * r) = o;
                     }
                 }
             }

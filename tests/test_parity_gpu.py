@@ -70,6 +70,8 @@ def _mk(V, H, groups=None, seed=0, **kw):
     (200, 96, 100, [(190, 200)]),  # batch > 64 (two M blocks), softmax group at the edge
     (300, 128, 64, [(10, 20), (290, 300)]),   # two groups, one straddling nothing, one at the end
     (1000, 260, 64, None),         # several split-K chunks
+    (384, 256, 130, None),         # three 64-row batch chunks: first / middle / last passes of the streaming update kernel
+    (1100, 132, 200, [(1090, 1100)]),   # four chunks on the split-K + bit-packed-samples path
 ])
 def test_philox_cd_step_matches_oracle(V, H, B, groups):
     """PHILOX mode: device draws == oracle/draws.py:PhiloxStream, so the whole update must agree."""
@@ -168,6 +170,33 @@ def test_free_energy_matches_oracle(V, H, B):
 def test_live_best_of_k_gpu():
     en = P.case_live_best_of_k(DEV, K=16)
     assert en.shape[0] == 16
+
+
+@pytest.mark.parametrize("B", [100, 200])
+def test_stats_then_apply_equals_fused_update_for_multi_chunk_batches(B, _native):
+    """Batches of several 64-row chunks: the statistics kernel accumulates over the chunks, the fused update applies
+    the same linear decomposition; both must agree (different rounding order only) and match the shard sum."""
+    from imdbn import engine as E
+    V, H = 640, 192
+    g = np.random.default_rng(2)
+    X = (g.random((B, V), dtype=F32) > 0.7).astype(F32)
+    r1, st, _ = _mk(V, H, None, seed=8)
+    r2, _, _ = _mk(V, H, None, seed=8)
+    with E.use_rng(E.PhiloxRng(seed=31)):
+        l1 = r1.train_epoch(P.T(X, DEV), 0, 1, CD=1)
+    packed = _native.cd_stats(r2, P.T(X, DEV), 1, E.PhiloxRng(seed=31))
+    half = (B // 2 + 7) // 8 * 8
+    s0 = _native.cd_stats(r2, P.T(X[:half], DEV), 1, E.PhiloxRng(seed=31, row0=0))
+    s1 = _native.cd_stats(r2, P.T(X[half:], DEV), 1, E.PhiloxRng(seed=31, row0=half))
+    assert_close(P.N(s0 + s1), P.N(packed), 2e-6, "shard sum of the statistics", atol=2e-5)
+    l2 = _native.apply_delta(r2, packed, B, 0.1, 0.5)
+    assert_close(float(l2), float(l1), 1e-5, "loss")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r2, k)), P.N(getattr(r1, k)), 1e-5, k, atol=2e-6)
+    o = O.train_epoch(st, X, 0, 1, PhiloxStream(31))
+    assert_close(float(l1), o, 1e-5, "loss vs oracle")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r1, k)), getattr(st, k), 1e-4, k, atol=2e-6)
 
 
 def test_products_are_fp32_exact():

@@ -27,3 +27,24 @@ out = {
 json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json"), "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
     print(f"{k[:60]:60s} {d['hbm_bytes_per_launch']/1e6:9.1f} MB/launch  x{d['launches']}")
+
+# matrix-core counters (separate passes): MfmaUtil [% of SIMD cycles the MFMA pipe is busy], MfmaFlopsBF16 per launch
+mf = collections.defaultdict(dict)
+for c in ("MfmaUtil", "MfmaFlopsBF16"):
+    fs = sorted(glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_{c}/**/*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    if not fs:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[-1])):
+        if r.get("Counter_Name") == c and "imdbn" in r["Kernel_Name"]:
+            acc[re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        mf[k][c + "_mean"] = sum(v) / len(v)
+        mf[k]["launches"] = len(v)
+if mf:
+    json.dump({"command": "rocprofv3 --pmc {MfmaUtil|MfmaFlopsBF16} (separate passes) -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline",
+               "note": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs) * 100; the update is bandwidth bound, the MFMA pipe is mostly idle by design "
+                       "(bf16 MFMA roofline of the whole update: 3.8 us of ~131 us)",
+               "kernels": dict(mf)}, open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json"), "w"), indent=1)
+    for k, d in mf.items():
+        print(f"{k[:60]:60s} MfmaUtil {d.get('MfmaUtil_mean', float('nan')):6.2f} %   bf16 flops/launch {d.get('MfmaFlopsBF16_mean', 0)/1e9:8.2f} G")

@@ -436,12 +436,15 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
         const int nchunk = L.Bp / 64;
         for (int ch = 0; ch < nchunk; ++ch) {
             f.b0 = 64 * ch;
-            f.pass = nchunk == 1 ? 0 : (ch == 0 ? 1 : (ch == nchunk - 1 ? 3 : 2));
+            const int pass = nchunk == 1 ? 0 : (ch == 0 ? 1 : (ch == nchunk - 1 ? 3 : 2));
             const int br = (ch == nchunk - 1) ? brows : 0;
             dim3 g(nh, cdiv(nv, tpb) + br);
-#define LAUNCH_K3(M, HTV) hipLaunchKernelGGL((assoc_update_planes<M, HTV>), g, dim3(256), 0, c.s, f, tpb, bb, br)
-            if (c.rt == 3) { if (mode_stats) LAUNCH_K3(1, 3); else LAUNCH_K3(0, 3); }
-            else           { if (mode_stats) LAUNCH_K3(1, 1); else LAUNCH_K3(0, 1); }
+#define LAUNCH_K3(M, HTV, PS) hipLaunchKernelGGL((assoc_update_planes<M, HTV, PS>), g, dim3(256), 0, c.s, f, tpb, bb, br)
+#define LAUNCH_K3_P(M, HTV) do { if (pass == 0) LAUNCH_K3(M, HTV, 0); else if (pass == 1) LAUNCH_K3(M, HTV, 1); \
+                                 else if (pass == 2) LAUNCH_K3(M, HTV, 2); else LAUNCH_K3(M, HTV, 3); } while (0)
+            if (c.rt == 3) { if (mode_stats) LAUNCH_K3_P(1, 3); else LAUNCH_K3_P(0, 3); }
+            else           { if (mode_stats) LAUNCH_K3_P(1, 1); else LAUNCH_K3_P(0, 1); }
+#undef LAUNCH_K3_P
 #undef LAUNCH_K3
         }
         HIPCHK(hipGetLastError());

@@ -526,13 +526,13 @@ struct AssocArgs {
     float lr, mom, wd, n;
     float* delta;
     int dbg;
-    // batches of more than one 64-row chunk: one launch per chunk, b0 = first batch row of this launch's chunk and
-    // pass = 0 single chunk | 1 first | 2 middle | 3 last.  The momentum update is linear in the statistics:
+    // batches of more than one 64-row chunk: one launch per chunk, b0 = first batch row of this launch's chunk; the kernel's
+    // PASS template argument = 0 single chunk | 1 first | 2 middle | 3 last.  The momentum update is linear in the statistics:
     //   first : W_m <- mom*W_m + lr*(d/n - wd*W)        (W untouched)
     //   middle: W_m <- W_m + lr*d/n
     //   last  : W_m <- W_m + lr*d/n ;  W <- W + W_m
     // (statistics mode: first writes delta, the others add to it)
-    int b0, pass;
+    int b0;
 };
 
 // All operand fragments of one 16-row batch block for this wave's 32(v) x 64(h) tile.
@@ -702,13 +702,13 @@ struct AssocPlanesArgs {
     float lr, mom, wd, n;
     float* delta;
     int dbg;
-    // batches of more than one 64-row chunk: one launch per chunk, b0 = first batch row of this launch's chunk and
-    // pass = 0 single chunk | 1 first | 2 middle | 3 last.  The momentum update is linear in the statistics:
+    // batches of more than one 64-row chunk: one launch per chunk, b0 = first batch row of this launch's chunk; the kernel's
+    // PASS template argument = 0 single chunk | 1 first | 2 middle | 3 last.  The momentum update is linear in the statistics:
     //   first : W_m <- mom*W_m + lr*(d/n - wd*W)        (W untouched)
     //   middle: W_m <- W_m + lr*d/n
     //   last  : W_m <- W_m + lr*d/n ;  W <- W + W_m
     // (statistics mode: first writes delta, the others add to it)
-    int b0, pass;
+    int b0;
 };
 
 __device__ __forceinline__ int k3_swz(int row, int c) { return row * K3_ROWB + ((c ^ ((row >> 1) & 7)) << 4); }
@@ -780,9 +780,9 @@ __device__ __forceinline__ void k3_mfma_wave(f32x16 (&acc)[4], const char* sH, c
 // tile collapses onto one row, unused slices are still loaded (clamped plane index, L2 hits).
 // After the hidden staging there is no block barrier: the four waves run independently and drift apart, which
 // smooths the load / store bursts.  One wave per SIMD (two 128-register weight tiles in flight).
-// One launch handles ONE 64-row batch chunk (a.b0); larger batches take one launch per chunk (a.pass).
+// One launch handles ONE 64-row batch chunk (a.b0); larger batches take one launch per chunk (template argument PASS).
 // Requires 16-B aligned weight rows; otherwise the generic kernel runs.
-template <int MODE, int HT>
+template <int MODE, int HT, int PASS>
 __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, int bx, int by, int tiles_per_block,
                                         int nap, int nan_) {
     const int P = nap + nan_;                                       // 2, 4 or 6 planes per tile
@@ -801,7 +801,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
     char* sV = smem + K3_VIS0 + w * (4 * K3_SLICE);                    // this wave's four slices
     const uint32_t sV_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sV);
 
-    const float* Wsrc = (a.pass == 2) ? a.Wm : a.W;            // middle passes do not need W: repeat the W_m address (same lines)
+    const float* Wsrc = (PASS == 2) ? a.Wm : a.W;              // middle passes do not need W: repeat the W_m address (same lines)
     auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0, bool valid) {
         if constexpr (MODE == 0) {
 #pragma unroll
@@ -812,7 +812,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
                 mo[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
             }
         } else {
-            if (a.pass >= 2) {                                   // statistics of a later batch chunk: add to delta
+            if constexpr (PASS >= 2) {                           // statistics of a later batch chunk: add to delta
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = valid ? min(v0 + 32 * w + mfma_row(reg, l), a.V - 1) : tile0 * 128;
@@ -904,7 +904,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
                         float4 m = mc[reg];
                         const float gx = POW2 ? d.x * inv_n : d.x / a.n, gy = POW2 ? d.y * inv_n : d.y / a.n;
                         const float gz = POW2 ? d.z * inv_n : d.z / a.n, gw = POW2 ? d.w * inv_n : d.w / a.n;
-                        if (a.pass <= 1) {                                               // single chunk, or the first of several
+                        if constexpr (PASS <= 1) {                                       // single chunk, or the first of several
                             m.x = m.x * a.mom; m.x = m.x + a.lr * (gx - a.wd * w0.x);        // rbm.py:212
                             m.y = m.y * a.mom; m.y = m.y + a.lr * (gy - a.wd * w0.y);
                             m.z = m.z * a.mom; m.z = m.z + a.lr * (gz - a.wd * w0.z);
@@ -913,11 +913,11 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
                             m.x = m.x + a.lr * gx; m.y = m.y + a.lr * gy; m.z = m.z + a.lr * gz; m.w = m.w + a.lr * gw;
                         }
                         *reinterpret_cast<float4*>(a.Wm + idx) = m;
-                        if (a.pass == 0 || a.pass == 3)
+                        if constexpr (PASS == 0 || PASS == 3)
                             *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
                     } else {
                         float4 o = d;
-                        if (a.pass >= 2) { const float4 p = mc[reg]; o = make_float4(p.x + d.x, p.y + d.y, p.z + d.z, p.w + d.w); }
+                        if constexpr (PASS >= 2) { const float4 p = mc[reg]; o = make_float4(p.x + d.x, p.y + d.y, p.z + d.z, p.w + d.w); }
                         *reinterpret_cast<float4*>(a.delta + (int64_t)row * a.H + h0 + 4 * r) = o;
                     }
                 }
@@ -932,7 +932,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
     }
 }
 
-template <int MODE, int HT>
+template <int MODE, int HT, int PASS>
 __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block,
                                                               const BiasArgs bias, int bias_rows) {
     __shared__ __attribute__((aligned(16))) char smem[K3_LDS_BYTES];      // 160 KB static: all of the CU's LDS
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
     const int ncbv = ((a.V + 15) / 16 * 16 + 63) / 64;
     const int nap = operand_terms(a.vpos_flag, ncbv, a.Bp / 8, (tile0 * 128) / 64, (tile0 + tiles_per_block) * 2, a.vpos_terms);
     const int nan_ = a.vneg_terms;
-    k3_body<MODE, HT>(a, smem, bx, by, tiles_per_block, nap, nan_);
+    k3_body<MODE, HT, PASS>(a, smem, bx, by, tiles_per_block, nap, nan_);
 }
 
 }  // namespace imdbn

@@ -8,8 +8,8 @@ A "step" is one complete ``RBM.train_epoch`` call (reference rbm.py:180-227) on 
 K1 -> K2 -> K1 -> K3 (+ epilogue kernels), called through the product's Python class exactly as
 ``iDBN.train`` calls it (idbn.py:202).  Inputs (16 distinct synthetic binary 100x100 "dot" frames
 batches, density 0.1) are resident in HBM before the timed region.  With N>1 each rank holds a
-full parameter replica and 64 rows of a 64*N global batch; one all-reduce (RCCL) of the packed
-statistics per step; `value` counts batch-64 updates per second summed over the ranks (= N x global steps/s,
+full parameter replica and 64 rows of a 64*N global batch; one exchange per step over RCCL (all-gather of the
+7 MB factor blocks by default, or all-reduce of the 60 MB packed statistics with --dp-mode allreduce); `value` counts batch-64 updates per second summed over the ranks (= N x global steps/s,
 weak scaling: 64 rows per GPU).
 
 One JSON line on rank 0.  `roofline` is for the dominant kernel (K3 assoc_update): algorithmic bytes
@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     ap.add_argument("--force-dp", action="store_true", help="take the stats/all-reduce/apply path even with one rank")
     ap.add_argument("--no-k3-events", action="store_true", help="do not bracket K3 with HIP events in the timed region")
+    ap.add_argument("--dp-mode", default="factors", choices=["factors", "allreduce"],
+                    help="data-parallel exchange: factor blocks (all-gather, ~7 MB/rank) or packed fp32 statistics (all-reduce, 60 MB)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank flow on one GPU)")
     args = ap.parse_args()
 
@@ -139,7 +141,7 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     if world > 1 or args.force_dp:
-        E.dp.enable(force=args.force_dp)
+        E.dp.enable(force=args.force_dp, mode=args.dp_mode)
 
     torch.manual_seed(0)
     rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
@@ -195,6 +197,7 @@ def main():
             "config": {"workload": "BASELINE configs[1] layer 1: RBM 10000<->1500 train_epoch, CD-1, batch 64 per GPU, "
                                    "fp32 master weights, lr 0.1 wd 1e-4 mom 0.5",
                        "global_batch": B * world, "parallelism": f"dp{world}",
+                       "dp_exchange": (args.dp_mode if (world > 1 or args.force_dp) else None),
                        "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
                        "final_loss": float(loss)},
             "global_steps_per_s": args.steps / dt,

@@ -173,6 +173,19 @@ int imdbn_rbm_cd_stats(const imdbn_rbm_desc* d, const float* data, int64_t ldd, 
 int imdbn_rbm_apply_delta(const imdbn_rbm_desc* d, const float* packed, int global_B,
                           const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream);
 
+/* ---- data-parallel "factor exchange" (alternative to cd_stats / all-reduce / apply_delta) -----------------
+ * The factors of <= 64 rows (visible / hidden operand planes, column sums, error partials: ~7 MB at 10000 x 1500)
+ * are 8x smaller than the fp32 delta-W (60 MB).  Every rank: cd_factors (the CD pass; the factor block stays in its
+ * workspace at imdbn_factor_block's offset), all-gather of the blocks, apply_factors (the update kernel runs once
+ * per rank block; identical arithmetic on every rank, replicas stay bit-identical).
+ * Needs <= 64 rows per rank, 16-B aligned weight rows, no softmax groups (IMDBN_E_UNSUPPORTED otherwise). */
+int    imdbn_factor_block(int V, int H, int B, size_t* offset, size_t* bytes);
+int    imdbn_rbm_cd_factors(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B, const imdbn_cd_opts* opts,
+                            imdbn_rng* rng, void* ws, size_t ws_bytes, imdbn_stream_t stream);
+int    imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n_ranks, size_t rank_stride,
+                               int rows_per_rank, int global_B, const imdbn_cd_opts* opts, float* loss_out,
+                               imdbn_stream_t stream);
+
 /* ---- K4: conditional chains (rbm.py:240-400) -------------------------------------------- */
 /* v0 = v_known*mask + (1-mask)*U (init_uniform=1) or v_known (0); then n_steps steps; out_v[B][V].
  * mu (nullable) is the [B][Dz] pull target of rbm.py:359-363. */

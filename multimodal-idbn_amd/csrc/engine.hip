@@ -94,6 +94,7 @@ struct Layout {
     float* f_v[2];
     float* cs_hpos; float* cs_hneg; float* cs_vpos; float* cs_vneg;
     float* loss_part; int n_loss_slots;
+    size_t fb_off, fb_bytes;      // the factor block inside the workspace
     ChainRec* chain_recs;   // per-step schedule of the row-parallel chain kernel
     bf16_t* k4_planes; int64_t k4_plane_stride;      // fragment-ordered bf16 weight planes [2 directions][3 terms]
     int down_tr;            // visible rows per block of the fused K2 (<= 32): balances the row tiles over the CUs
@@ -145,12 +146,27 @@ Layout make_layout(int V, int H, int B, char* base) {
     size_t off = 0;
     auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return p; };
     // exactness maps of caller-supplied operands (prep rewrites them every call): visible side, hidden side
+    // ---- factor block: everything the weight / bias update needs from one CD pass, contiguous, so that the
+    // data-parallel "factor exchange" can all-gather it in one piece (imdbn_factor_block): exactness map of the data,
+    // hidden planes (pos, negated neg), column-sum and squared-error partials, visible planes (pos: 3 terms; neg: its
+    // FIRST term only is inside the block -- the negative visible state of train_epoch is a sample, one term)
+    L.fb_off = off;
     L.flags = (int*)take((size_t)L.P * cdiv(L.Vpad, 64) * 4);
+    for (int i = 0; i < 2; ++i) L.hid_tr[i] = (bf16_t*)take((size_t)3 * H * L.Bp * 2);
+    L.cs_hpos = (float*)take((size_t)L.P * H * 4);
+    L.cs_hneg = (float*)take((size_t)L.P * H * 4);
+    L.cs_vpos = (float*)take((size_t)L.P * V * 4);
+    L.cs_vneg = (float*)take((size_t)L.P * V * 4);
+    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 16) * (L.Bp / 64)) + IMDBN_MAX_GROUPS * (L.Bp / 64);
+    L.loss_part = (float*)take((size_t)L.n_loss_slots * 4);
+    for (int i = 0; i < 2; ++i) {
+        L.vis_tr[i] = (bf16_t*)take((size_t)3 * V * L.Bp * 2);
+        if (i == 1) L.fb_bytes = (off - (((size_t)3 * V * L.Bp * 2 + 255) / 256 * 256)) + ((size_t)V * L.Bp * 2 + 255) / 256 * 256 - L.fb_off;
+    }
+    // ---- the rest
     L.flags_h = (int*)take((size_t)L.P * cdiv(L.Hpad, 64) * 4);
     for (int i = 0; i < 2; ++i) L.vis_rm[i] = (bf16_t*)take((size_t)3 * L.Bp * L.Vpad * 2);
-    for (int i = 0; i < 2; ++i) L.vis_tr[i] = (bf16_t*)take((size_t)3 * V * L.Bp * 2);
     L.hid_rm = (bf16_t*)take((size_t)3 * L.Bp * L.Hpad * 2);
-    for (int i = 0; i < 2; ++i) L.hid_tr[i] = (bf16_t*)take((size_t)3 * H * L.Bp * 2);
     L.ldbits = 2 * cdiv(L.Hpad, 64);
     L.hid_bits = (uint32_t*)take((size_t)L.Bp * L.ldbits * 4);
     const size_t pf = std::max((size_t)L.up.ks * L.Bp * H, (size_t)L.down.ks * L.Bp * V);
@@ -158,12 +174,6 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.f_h = (float*)take((size_t)L.Bp * H * 4);
     L.f_vp = (float*)take((size_t)L.Bp * V * 4);
     for (int i = 0; i < 2; ++i) L.f_v[i] = (float*)take((size_t)L.Bp * V * 4);
-    L.cs_hpos = (float*)take((size_t)L.P * H * 4);
-    L.cs_hneg = (float*)take((size_t)L.P * H * 4);
-    L.cs_vpos = (float*)take((size_t)L.P * V * 4);
-    L.cs_vneg = (float*)take((size_t)L.P * V * 4);
-    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 16) * (L.Bp / 64)) + IMDBN_MAX_GROUPS * (L.Bp / 64);
-    L.loss_part = (float*)take((size_t)L.n_loss_slots * 4);
     L.chain_recs = (ChainRec*)take(sizeof(ChainRec) * CHAIN_MAX_STEPS);
     L.k4_plane_stride = 0; L.k4_planes = nullptr;
     if (V <= 1024 && H <= 1024) {
@@ -862,6 +872,87 @@ int imdbn_rbm_cd_stats(const imdbn_rbm_desc* d, const float* data, int64_t ldd, 
     p.hpos = c.L.cs_hpos; p.hneg = c.L.cs_hneg; p.vpos = c.L.cs_vpos; p.vneg = c.L.cs_vneg; p.P = c.L.P;
     p.loss_part = c.L.loss_part; p.n_loss = n_loss_used(c, false);
     hipLaunchKernelGGL(pack_stats, dim3(cdiv(std::max(d->V, d->H), 256) + 1), dim3(256), 0, c.s, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- data-parallel "factor exchange" ----------------------------------------------------------
+// The statistics are linear in the per-row factors, and the factors of 64 rows (7 MB at 10000 x 1500) are 8x
+// smaller than the fp32 delta-W (60 MB): every rank all-gathers the factor blocks and runs the streaming update
+// kernel once per rank block (first / middle / last pass) -- the same kernel, bits and order on every rank.
+int imdbn_factor_block(int V, int H, int B, size_t* offset, size_t* bytes) {
+    if (V <= 0 || H <= 0 || B <= 0 || !offset || !bytes) return fail(IMDBN_E_INVALID, "factor_block: bad argument");
+    const Layout L = make_layout(V, H, B, nullptr);
+    *offset = L.fb_off; *bytes = L.fb_bytes;
+    return 0;
+}
+
+static bool factor_mode_ok(const imdbn_rbm_desc* d, int B, bool with_momentum) {
+    return B >= 1 && B <= 64 && d->H % 4 == 0 && d->H >= 4 && d->ldw % 4 == 0 && (((uintptr_t)d->W) & 15) == 0 &&
+           (!with_momentum || (d->W_m && (((uintptr_t)d->W_m) & 15) == 0)) && d->n_groups == 0;
+}
+
+int imdbn_rbm_cd_factors(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B, const imdbn_cd_opts* o,
+                         imdbn_rng* rng, void* ws, size_t ws_bytes, imdbn_stream_t stream) {
+    CHK(check_desc(d, false));
+    if (!data || !o || ldd < d->V) return fail(IMDBN_E_INVALID, "cd_factors: bad argument");
+    if (!factor_mode_ok(d, B, false)) return fail(IMDBN_E_UNSUPPORTED, "cd_factors: needs <= 64 rows per rank, 16-B aligned weight rows, no softmax groups");
+    Ctx c(d, rng, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    CHK(cd_phases(c, data, ldd, o));
+    return c.rng.finish();
+}
+
+int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n_ranks, size_t rank_stride, int rows_per_rank,
+                            int global_B, const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream) {
+    CHK(check_desc(d, true));
+    if (!gathered || !o || n_ranks < 1 || global_B <= 0) return fail(IMDBN_E_INVALID, "apply_factors: bad argument");
+    if (!factor_mode_ok(d, rows_per_rank, true)) return fail(IMDBN_E_UNSUPPORTED, "apply_factors: needs <= 64 rows per rank, 16-B aligned weight rows, no softmax groups");
+    Ctx c(d, nullptr, S(stream));
+    const Layout L0 = make_layout(d->V, d->H, rows_per_rank, nullptr);          // offsets of the factor block
+    if (rank_stride < L0.fb_bytes || (rank_stride & 255) || (((uintptr_t)gathered) & 255))
+        return fail(IMDBN_E_INVALID, "apply_factors: the gathered blocks must be 256-B aligned and at least %zu bytes apart", L0.fb_bytes);
+    // carve the layout over a base chosen so that its factor block IS rank 0's gathered block (nothing outside the
+    // block is touched here)
+    c.L = make_layout(d->V, d->H, rows_per_rank, const_cast<char*>((const char*)gathered) - L0.fb_off);
+    const Layout& L = c.L;
+    auto at = [&](const void* layout_ptr, int rk) { return (const char*)layout_ptr + (size_t)rk * rank_stride; };
+    AssocPlanesArgs f;
+    memset(&f, 0, sizeof(f));
+    f.W = d->W; f.Wm = d->W_m; f.ldw = d->ldw; f.V = L.V; f.H = L.H;
+    f.vpos_terms = c.nw == 1 ? 1 : 0; f.vneg_terms = 1;
+    f.vts = (int64_t)L.V * L.Bp; f.hts = (int64_t)L.H * L.Bp; f.Bp = L.Bp;
+    f.lr = o->lr; f.mom = o->momentum; f.wd = o->weight_decay; f.n = (float)global_B;
+    BiasArgs b;
+    memset(&b, 0, sizeof(b));
+    b.hid_bias = d->hid_bias; b.hb_m = d->hb_m; b.H = L.H; b.vis_bias = d->vis_bias; b.vb_m = d->vb_m; b.V = L.V;
+    b.hpos = (const float*)at(L.cs_hpos, 0); b.hneg = (const float*)at(L.cs_hneg, 0);
+    b.vpos = (const float*)at(L.cs_vpos, 0); b.vneg = (const float*)at(L.cs_vneg, 0);
+    b.P = L.P; b.lr = o->lr; b.mom = o->momentum; b.n = (float)global_B;
+    b.sparsity = o->sparsity ? 1 : 0; b.target = o->sparsity_target;
+    b.loss_part = (const float*)at(L.loss_part, 0); b.n_loss = n_loss_used(c, false);
+    b.loss_den = (float)global_B * (float)L.V; b.loss_out = loss_out;
+    b.R = n_ranks; b.rs = (int64_t)(rank_stride / 4);
+    BiasArgs bz;
+    memset(&bz, 0, sizeof(bz));
+    const int nh = cdiv(L.H, 128), nv = cdiv(L.V, 128);
+    const int tpb = std::max(1, cdiv(nh * nv, std::max(cu_count(), 1)));
+    const int brows = nh >= 2 ? 1 : 2;
+    for (int rk = 0; rk < n_ranks; ++rk) {
+        f.vpos = (const bf16_t*)at(L.vis_tr[0], rk); f.vpos_flag = (const int*)at(L.flags, rk);
+        f.hpos = (const bf16_t*)at(L.hid_tr[0], rk);
+        f.vneg = (const bf16_t*)at(L.vis_tr[1], rk); f.hneg = (const bf16_t*)at(L.hid_tr[1], rk);
+        const int pass = n_ranks == 1 ? 0 : (rk == 0 ? 1 : (rk == n_ranks - 1 ? 3 : 2));
+        const int br = (rk == n_ranks - 1) ? brows : 0;
+        const BiasArgs& bb = br ? b : bz;
+        dim3 g(nh, cdiv(nv, tpb) + br);
+#define LAUNCH_K3F(HTV, PS) hipLaunchKernelGGL((assoc_update_planes<0, HTV, PS>), g, dim3(256), 0, c.s, f, tpb, bb, br)
+#define LAUNCH_K3F_P(HTV) do { if (pass == 0) LAUNCH_K3F(HTV, 0); else if (pass == 1) LAUNCH_K3F(HTV, 1); \
+                               else if (pass == 2) LAUNCH_K3F(HTV, 2); else LAUNCH_K3F(HTV, 3); } while (0)
+        if (c.rt == 3) LAUNCH_K3F_P(3); else LAUNCH_K3F_P(1);
+#undef LAUNCH_K3F_P
+#undef LAUNCH_K3F
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -553,6 +553,7 @@ struct BiasArgs {
     float* vis_bias; float* vb_m; int V; const float* vpos; const float* vneg;
     int P; float lr, mom, n; int sparsity; float target;
     const float* loss_part; int n_loss; float loss_den; float* loss_out;
+    int R; int64_t rs;           // factor-exchange mode: the partials of R ranks, rs floats apart (R <= 1: one set)
 };
 
 __device__ __forceinline__ float sum_parts(const float* p, int P, int len, int i) {
@@ -588,14 +589,16 @@ __device__ __forceinline__ double loss_total_256(const float* part, int n, doubl
 __device__ __forceinline__ void bias_work(const BiasArgs& a, int blk, int nblk, double* sh) {
     if (blk == nblk - 1) {
         if (a.loss_out) {
-            const double t = loss_total_256(a.loss_part, a.n_loss, sh);
+            double t = 0.0;
+            for (int rk = 0; rk < max(a.R, 1); ++rk) { t += loss_total_256(a.loss_part + rk * a.rs, a.n_loss, sh); __syncthreads(); }
             if (threadIdx.x == 0) a.loss_out[0] = (float)(t / (double)a.loss_den);      // rbm.py:226
         }
         return;
     }
     for (int i = blk * 256 + threadIdx.x; i < max(a.V, a.H); i += (nblk - 1) * 256) {
         if (i < a.H) {
-            const float sp = sum_parts(a.hpos, a.P, a.H, i), sn = sum_parts(a.hneg, a.P, a.H, i);
+            float sp = 0.f, sn = 0.f;
+            for (int rk = 0; rk < max(a.R, 1); ++rk) { sp += sum_parts(a.hpos + rk * a.rs, a.P, a.H, i); sn += sum_parts(a.hneg + rk * a.rs, a.P, a.H, i); }
             float m = a.hb_m[i] * a.mom;
             m = m + (a.lr * (sp - sn)) / a.n;                                   // rbm.py:216
             if (a.sparsity) m = m + (-a.lr) * (sp / a.n - a.target);           // rbm.py:218-219
@@ -603,7 +606,8 @@ __device__ __forceinline__ void bias_work(const BiasArgs& a, int blk, int nblk, 
             a.hid_bias[i] += m;
         }
         if (i < a.V) {
-            const float sp = sum_parts(a.vpos, a.P, a.V, i), sn = sum_parts(a.vneg, a.P, a.V, i);
+            float sp = 0.f, sn = 0.f;
+            for (int rk = 0; rk < max(a.R, 1); ++rk) { sp += sum_parts(a.vpos + rk * a.rs, a.P, a.V, i); sn += sum_parts(a.vneg + rk * a.rs, a.P, a.V, i); }
             float m = a.vb_m[i] * a.mom;
             m = m + (a.lr * (sp - sn)) / a.n;                                   // rbm.py:223
             a.vb_m[i] = m;

@@ -14,25 +14,36 @@ import torch
 _group = None
 _enabled = False
 _force = False
+_mode = "factors"
 
 
-def enable(group=None, force: bool = False):
+def enable(group=None, force: bool = False, mode: str = "factors"):
     """Turn on data-parallel updates (requires an initialised torch.distributed).
 
-    ``force=True`` takes the stats -> all-reduce -> apply path even with a single rank (used to
-    exercise the RCCL path on a one-GPU box)."""
-    global _group, _enabled, _force
+    ``mode``: ``"factors"`` (default) all-gathers each rank's factor block (operand planes, column sums, error
+    partials: ~7 MB per 64 rows at 10000 x 1500) and every rank runs the update kernel once per rank block;
+    ``"allreduce"`` all-reduces the packed fp32 statistics (60 MB at that shape).  The factor exchange needs
+    <= 64 rows per rank, 16-B aligned weight rows and no softmax groups; other cases take the all-reduce path.
+    ``force=True`` takes the data-parallel path even with a single rank (to exercise it on a one-GPU box)."""
+    global _group, _enabled, _force, _mode
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("imdbn.engine.dp.enable(): torch.distributed is not initialised")
+    if mode not in ("factors", "allreduce"):
+        raise ValueError("mode must be 'factors' or 'allreduce'")
     _group = group
     _enabled = True
     _force = bool(force)
+    _mode = mode
 
 
 def disable():
-    global _group, _enabled, _force
-    _group, _enabled, _force = None, False, False
+    global _group, _enabled, _force, _mode
+    _group, _enabled, _force, _mode = None, False, False, "factors"
+
+
+def mode() -> str:
+    return _mode
 
 
 def active() -> bool:
@@ -56,3 +67,10 @@ def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
     import torch.distributed as dist
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group)
     return t
+
+
+def all_gather_blocks(out: torch.Tensor, block: torch.Tensor) -> torch.Tensor:
+    """out[r] = rank r's block (out: [world, n] uint8, contiguous)."""
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(out.view(-1), block.contiguous(), group=_group)
+    return out

@@ -273,6 +273,55 @@ class HipEngine:
         self._done(rng, r, sched)
         return packed
 
+    # ---- data-parallel factor exchange (include/imdbn_engine.h) --------------------------------------
+    def factor_block(self, V, H, B):
+        """(offset, bytes) of the factor block inside the workspace of an (V, H, B) call."""
+        off, nb = C.c_size_t(0), C.c_size_t(0)
+        N.check(self._lib.imdbn_factor_block(int(V), int(H), int(B), C.byref(off), C.byref(nb)), "imdbn_factor_block")
+        return int(off.value), int(nb.value)
+
+    def factor_mode_ok(self, rbm, B) -> bool:
+        W = rbm.W.data
+        return (W.is_cuda and 1 <= B <= 64 and W.shape[1] % 4 == 0 and W.stride(0) % 4 == 0 and W.data_ptr() % 16 == 0
+                and not self._groups(rbm))
+
+    def cd_factors(self, rbm, data, cd_k, rng) -> torch.Tensor:
+        """The CD pass of this rank's rows; returns the factor block (a uint8 VIEW of the workspace: consume it --
+        e.g. all-gather it -- before the next engine call on this RBM shape)."""
+        d = self._desc(rbm, False)
+        x = _f32c(data, "data")
+        B, dev = x.size(0), x.device
+        o = self._opts(rbm, 0.0, 0.0, cd_k)
+        sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
+        r, keep = self._rng(rng, sched, B, dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_cd_factors(C.byref(d), _ptr(x), x.stride(0), B, C.byref(o), C.byref(r), _ptr(ws), ws.numel(),
+                                                self._stream(dev)), "imdbn_rbm_cd_factors")
+        self._done(rng, r, sched)
+        off, nb = self.factor_block(d.V, d.H, B)
+        return ws[off:off + nb]
+
+    def gather_buffer(self, rbm, B, world) -> torch.Tensor:
+        """Reusable [world, block bytes] uint8 buffer for the all-gather of the factor blocks."""
+        W = rbm.W.data
+        _, nb = self.factor_block(W.shape[0], W.shape[1], B)
+        key = ("gather", W.device, W.shape[0], W.shape[1], B, world)
+        buf = self._ws.get(key)
+        if buf is None:
+            buf = self._ws[key] = torch.empty(world, nb, dtype=torch.uint8, device=W.device)
+        return buf
+
+    def apply_factors(self, rbm, gathered, rows_per_rank, global_B, lr, mom):
+        d = self._desc(rbm, True)
+        dev = gathered.device
+        o = self._opts(rbm, lr, mom, 1, sparsity=getattr(rbm, "sparsity", False))
+        loss = torch.empty(1, device=dev)
+        assert gathered.dtype == torch.uint8 and gathered.dim() == 2 and gathered.is_contiguous()
+        N.check(self._lib.imdbn_rbm_apply_factors(C.byref(d), _ptr(gathered), int(gathered.size(0)), int(gathered.stride(0)),
+                                                   int(rows_per_rank), int(global_B), C.byref(o), _ptr(loss), self._stream(dev)),
+                "imdbn_rbm_apply_factors")
+        return loss.reshape(())
+
     def apply_delta(self, rbm, packed, global_B, lr, mom):
         d = self._desc(rbm, True)
         dev = packed.device

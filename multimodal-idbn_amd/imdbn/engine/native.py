@@ -74,6 +74,9 @@ SIGNATURES = {
     "imdbn_packed_delta_floats": (_SZ, [_INT, _INT]),
     "imdbn_rbm_cd_stats": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
     "imdbn_rbm_apply_delta": (_INT, [C.POINTER(RbmDesc), _P, _INT, C.POINTER(CdOpts), _P, _P]),
+    "imdbn_factor_block": (_INT, [_INT, _INT, _INT, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "imdbn_rbm_cd_factors": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _SZ, _P]),
+    "imdbn_rbm_apply_factors": (_INT, [C.POINTER(RbmDesc), _P, _INT, _SZ, _INT, _INT, C.POINTER(CdOpts), _P, _P]),
     "imdbn_rbm_chain": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
                                C.POINTER(Rng), _P, _I64, _P, _SZ, _P]),
     "imdbn_rbm_clamped_step": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,

@@ -145,8 +145,9 @@ class RBM(nn.Module):
         """One CD-k update on one mini-batch (the name is the reference's); returns the 0-d MSE loss.
 
         With data parallelism enabled (``imdbn.engine.dp.enable()``) ``data`` is this rank's shard
-        of the global batch: statistics are all-reduced once and every replica applies the same
-        update with 1/global_batch.
+        of the global batch: the ranks exchange their factor blocks (or all-reduce the statistics, see
+        ``imdbn.engine.dp.enable``) once and every replica applies the same update with 1/global_batch
+        (SURVEY.md 8e).
         """
         lr, mom = self._lr_mom(epoch)
         eng, rng, x = self._eng(), _E.get_rng(), self._in(data)
@@ -155,6 +156,11 @@ class RBM(nn.Module):
             B = x.size(0)
             if isinstance(rng, _E.PhiloxRng):
                 rng.row0 = dp.rank() * B
+            if dp.mode() == "factors" and hasattr(eng, "factor_mode_ok") and eng.factor_mode_ok(self, B):
+                # exchange the factors (~7 MB per rank at 10000 x 1500) instead of the fp32 statistics (60 MB)
+                block = eng.cd_factors(self, x, CD, rng)
+                gathered = dp.all_gather_blocks(eng.gather_buffer(self, B, dp.world_size()), block)
+                return eng.apply_factors(self, gathered, B, B * dp.world_size(), lr, mom)
             buf = eng.packed_buffer(self) if hasattr(eng, "packed_buffer") else None
             packed = eng.cd_stats(self, x, CD, rng, out=buf)
             dp.all_reduce_sum(packed)

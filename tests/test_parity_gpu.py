@@ -199,6 +199,43 @@ def test_stats_then_apply_equals_fused_update_for_multi_chunk_batches(B, _native
         assert_close(P.N(getattr(r1, k)), getattr(st, k), 1e-4, k, atol=2e-6)
 
 
+@pytest.mark.parametrize("V,H,R,Bl", [(640, 192, 2, 64), (2048, 512, 3, 64), (640, 192, 4, 40)])
+def test_factor_exchange_equals_single_process_and_allreduce_updates(V, H, R, Bl, _native):
+    """Data-parallel factor exchange, emulated on one device: R ranks of Bl rows each run cd_factors (Philox keyed
+    on the global row), the blocks are "gathered" by copies, apply_factors runs the update kernel once per rank
+    block.  Must equal (a) the single-process update of the R*Bl-row batch and (b) the all-reduce path."""
+    from imdbn import engine as E
+    g = np.random.default_rng(4)
+    B = R * Bl
+    X = (g.random((B, V), dtype=F32) > 0.75).astype(F32)
+    X[:, ::7] = g.random((B, len(range(0, V, 7))), dtype=F32)          # some real-valued columns: three-term planes
+    r1, st, _ = _mk(V, H, None, seed=6, sparsity=True, sparsity_factor=0.1)
+    r2, _, _ = _mk(V, H, None, seed=6, sparsity=True, sparsity_factor=0.1)
+    r3, _, _ = _mk(V, H, None, seed=6, sparsity=True, sparsity_factor=0.1)
+    lr, mom = r1._lr_mom(0)
+    with E.use_rng(E.PhiloxRng(seed=77)):
+        l1 = r1.train_epoch(P.T(X, DEV), 0, 1, CD=1)
+    assert _native.factor_mode_ok(r2, Bl)
+    gathered = _native.gather_buffer(r2, Bl, R)
+    for rk in range(R):
+        blk = _native.cd_factors(r2, P.T(X[rk * Bl:(rk + 1) * Bl], DEV), 1, E.PhiloxRng(seed=77, row0=rk * Bl))
+        gathered[rk].copy_(blk)
+    l2 = _native.apply_factors(r2, gathered, Bl, B, lr, mom)
+    packed = None
+    for rk in range(R):
+        s = _native.cd_stats(r3, P.T(X[rk * Bl:(rk + 1) * Bl], DEV), 1, E.PhiloxRng(seed=77, row0=rk * Bl)).clone()
+        packed = s if packed is None else packed + s
+    l3 = _native.apply_delta(r3, packed, B, lr, mom)
+    assert_close(np.array([float(l2), float(l3)], F32), np.array([float(l1)] * 2, F32), 1e-5, "losses")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r2, k)), P.N(getattr(r1, k)), 1e-5, "factors vs single: " + k, atol=2e-6)
+        assert_close(P.N(getattr(r3, k)), P.N(getattr(r1, k)), 1e-5, "allreduce vs single: " + k, atol=2e-6)
+    o = O.train_epoch(st, X, 0, 1, PhiloxStream(77))
+    assert_close(float(l2), o, 1e-5, "loss vs oracle")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r2, k)), getattr(st, k), 1e-4, "factors vs oracle: " + k, atol=2e-6)
+
+
 def test_products_are_fp32_exact():
     """bf16x3 split: v@W against float64 must be at fp32 rounding level (not bf16 level)."""
     r, st, g = _mk(2000, 300, None, seed=11)

@@ -162,9 +162,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    sync()
+    try:
+        for i in range(args.warmup):
+            step(i)
+        sync()
+    except Exception as e:          # the factor exchange has preconditions (imdbn.engine.dp.enable); the all-reduce path has none
+        if not ((world > 1 or args.force_dp) and args.dp_mode == "factors"):
+            raise
+        print(f"[bench] rank {rank}: factor exchange failed ({type(e).__name__}: {e}); using the all-reduce exchange", file=sys.stderr, flush=True)
+        args.dp_mode = "allreduce"
+        E.dp.enable(force=args.force_dp, mode="allreduce")
+        for i in range(args.warmup):
+            step(i)
+        sync()
     if world == 1 and not args.no_k3_events:
         eng.profile(True)
     t0 = time.perf_counter()

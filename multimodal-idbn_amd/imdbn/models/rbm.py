@@ -12,6 +12,7 @@ of torch's global generator; all returned tensors are grad-less.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -21,9 +22,13 @@ from imdbn import engine as _E
 
 
 def _row_pitch(h: int) -> int:
-    """Row pitch in elements: H rounded up to 32 floats (128 B) when that costs < 7 % extra memory."""
-    p = (h + 31) // 32 * 32
-    return p if (p - h) * 16 <= h else h
+    """Row pitch in elements: H rounded up to 128 floats (512 B: the row segment one half-wave of the update kernel
+    reads and writes) or else to 32 floats (128 B), whichever costs < 7 % extra memory."""
+    for q in (int(os.environ.get("IMDBN_ROW_PITCH", "128")), 32):
+        p = (h + q - 1) // q * q
+        if (p - h) * 16 <= h:
+            return p
+    return h
 
 
 def _step(T=1.0, sigma=0.0, eta=0.0, sample_h=False, vmode=0, clamp=True) -> dict:

@@ -932,6 +932,157 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
     }
 }
 
+// ---- data-parallel factor exchange: the rank blocks are looped INSIDE the tile ------------------------------
+// One launch per rank block (PASS 1/2/3 above) re-reads and re-writes W_m for every rank: 46 + 29 (R - 1) us.
+// Here the statistics of all R gathered blocks are accumulated in the MFMA accumulators of one tile before its single
+// read-modify-write: the weights move once whatever R is.  Per (tile, rank) the block restages that rank's hidden
+// planes (96 KB from L2, LDS-DMA) and its visible slices; two block barriers per rank (the hidden planes are shared
+// by the four waves), so the barrier-free schedule of the single-block kernel does not apply here.
+struct RankLoopArgs { int n_ranks; int64_t stride; };      // stride: elements (bf16) between the rank blocks' operands; flags: stride/2 ints
+
+template <int HT>
+__device__ __forceinline__ void k3_body_ranks(const AssocPlanesArgs& a, const RankLoopArgs& rl, char* smem, int bx, int by,
+                                              int tiles_per_block, int nap, int nan_) {
+    const int P = nap + nan_;                                       // planes per tile and rank: 2 or 4 (host guarantees <= 4)
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, kh = l >> 5;
+    const int h0 = bx * 128;
+    const int tile0 = by * tiles_per_block;
+    const int n_vtiles = (a.V + 127) / 128;
+    const int n_my = min(tiles_per_block, n_vtiles - tile0);
+    const int colc = min(h0 + 4 * r, a.H - 4);
+    const bool cok = (h0 + 4 * r) < a.H;
+    const bool n_pow2 = (__float_as_uint(a.n) & 0x7fffffu) == 0u;
+    const float inv_n = 1.0f / a.n;
+    char* sHp = smem;
+    char* sHn = smem + 3 * K3_PLANE;
+    char* sV = smem + K3_VIS0 + w * (4 * K3_SLICE);
+    const uint32_t sV_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sV);
+    const uint32_t sH_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+
+    auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0, bool valid) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = valid ? min(v0 + 32 * w + mfma_row(reg, l), a.V - 1) : tile0 * 128;
+            const int64_t idx = (int64_t)row * a.ldw + colc;
+            wo[reg] = *reinterpret_cast<const float4*>(a.W + idx);
+            mo[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
+        }
+    };
+    auto dma_rank = [&](int rk, int v0w) {                          // hidden planes + this wave's visible slices of rank rk
+        const int64_t ro = (int64_t)rk * rl.stride;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int tb = 0; tb < HT; ++tb)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = 4 * w + jj, i = 64 * j + l, lrow = i >> 3, pos = i & 7;
+                    const int row = 4 * (lrow & 31) + (lrow >> 5), c = pos ^ ((lrow >> 1) & 7);
+                    const bf16_t* src = (ph ? a.hneg : a.hpos) + ro + tb * a.hts + (int64_t)min(h0 + row, a.H - 1) * a.Bp + 8 * c;
+                    k3_dma16(src, sH_lds + (3 * ph + tb) * K3_PLANE + j * 1024);
+                }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int pl = min(p, P - 1);
+            const bf16_t* src = (pl < nap ? a.vpos + pl * a.vts : a.vneg + (pl - nap) * a.vts) + ro;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = l + 64 * q, row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
+                k3_dma16(src + (int64_t)min(v0w + row, a.V - 1) * a.Bp + 8 * c, sV_lds + p * K3_SLICE + q * 1024);
+            }
+        }
+    };
+
+    float4 wA[16], mA[16], wB[16], mB[16];
+    load_tile(wA, mA, tile0 * 128, true);
+    auto tile = [&](int it, float4 (&wc)[16], float4 (&mc)[16], float4 (&wn)[16], float4 (&mn)[16]) {
+        const int v0 = (tile0 + it) * 128;
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int rk = 0; rk < rl.n_ranks; ++rk) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                                         // every wave is done with the previous rank's planes
+            dma_rank(rk, v0 + 32 * w);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rk == 0) {                                           // next tile's weights: behind this rank's planes in the VMEM queue
+                load_tile(wn, mn, v0 + 128, it + 1 < n_my);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // later ranks' planes queue behind the prefetch: it has had a rank's time
+            }
+            __syncthreads();                                         // the hidden planes (staged by all four waves) are complete
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (p < P) k3_mfma_wave<HT>(acc, p < nap ? sHp : sHn, sV + p * K3_SLICE, r, kh);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        auto epilogue = [&](auto pow2_tag) {
+            constexpr bool POW2 = decltype(pow2_tag)::value;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = v0 + 32 * w + mfma_row(reg, l);
+                if (row < a.V && cok) {
+                    const float4 d = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
+                    const int64_t idx = (int64_t)row * a.ldw + h0 + 4 * r;
+                    const float4 w0 = wc[reg];
+                    float4 m = mc[reg];
+                    const float gx = POW2 ? d.x * inv_n : d.x / a.n, gy = POW2 ? d.y * inv_n : d.y / a.n;
+                    const float gz = POW2 ? d.z * inv_n : d.z / a.n, gw = POW2 ? d.w * inv_n : d.w / a.n;
+                    m.x = m.x * a.mom; m.x = m.x + a.lr * (gx - a.wd * w0.x);        // rbm.py:212
+                    m.y = m.y * a.mom; m.y = m.y + a.lr * (gy - a.wd * w0.y);
+                    m.z = m.z * a.mom; m.z = m.z + a.lr * (gz - a.wd * w0.z);
+                    m.w = m.w * a.mom; m.w = m.w + a.lr * (gw - a.wd * w0.w);
+                    *reinterpret_cast<float4*>(a.Wm + idx) = m;
+                    *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
+                }
+            }
+        };
+        if (n_pow2) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    };
+    for (int it = 0; it < n_my; it += 2) {
+        tile(it, wA, mA, wB, mB);
+        if (it + 1 < n_my) tile(it + 1, wB, mB, wA, mA);
+    }
+}
+
+template <int HT>
+__global__ __launch_bounds__(256, 1) void assoc_update_planes_ranks(const AssocPlanesArgs a, const RankLoopArgs rl, int tiles_per_block,
+                                                                    const BiasArgs bias, int bias_rows) {
+    __shared__ __attribute__((aligned(16))) char smem[K3_LDS_BYTES];
+    if (bias_rows > 0 && (int)blockIdx.y >= (int)gridDim.y - bias_rows) {
+        bias_work(bias, (blockIdx.y - (gridDim.y - bias_rows)) * gridDim.x + blockIdx.x, bias_rows * gridDim.x,
+                  reinterpret_cast<double*>(smem));
+        return;
+    }
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nbx = gridDim.x, nby = gridDim.y - bias_rows;
+        int xa = 0;
+        if (nbx % 2 == 0 && nby % 4 == 0) xa = 2; else if (nbx % 4 == 0 && nby % 2 == 0) xa = 4;
+        else if (nby % 8 == 0) xa = 1; else if (nbx % 8 == 0) xa = 8;
+        if (xa) {
+            const int xc = 8 / xa, sa = nbx / xa, sc = nby / xc;
+            const int p = blockIdx.y * nbx + blockIdx.x;
+            const int xcd = p & 7, slot = p >> 3;
+            bx = (xcd % xa) * sa + slot % sa;
+            by = (xcd / xa) * sc + slot / sa;
+        }
+    }
+    const int tile0 = by * tiles_per_block;
+    const int ncbv = ((a.V + 15) / 16 * 16 + 63) / 64;
+    int nap = a.vpos_terms;
+    if (nap == 0) {                                                  // any rank with inexact data in these tiles -> three terms for all
+        nap = 1;
+        for (int rk = 0; rk < rl.n_ranks; ++rk)
+            nap = max(nap, operand_terms(a.vpos_flag + rk * (rl.stride / 2), ncbv, a.Bp / 8, (tile0 * 128) / 64, (tile0 + tiles_per_block) * 2, 0));
+    }
+    k3_body_ranks<HT>(a, rl, smem, bx, by, tiles_per_block, nap, a.vneg_terms);
+}
+
 template <int MODE, int HT, int PASS>
 __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block,
                                                               const BiasArgs bias, int bias_rows) {

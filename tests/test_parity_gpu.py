@@ -236,6 +236,45 @@ def test_factor_exchange_equals_single_process_and_allreduce_updates(V, H, R, Bl
         assert_close(P.N(getattr(r2, k)), getattr(st, k), 1e-4, "factors vs oracle: " + k, atol=2e-6)
 
 
+def _random_cases():
+    g = np.random.default_rng(20261004)
+    cases = []
+    for _ in range(8):
+        V = int(g.integers(17, 1400)); H = int(g.integers(5, 400)); B = int(g.integers(1, 150))
+        if g.random() < 0.5:
+            H = H // 4 * 4 + 4                                   # aligned rows: float4 kernels
+        groups = None
+        if g.random() < 0.4 and V > 40:
+            wd = int(g.integers(2, 33))
+            groups = [(V - wd, V)]
+        cases.append((V, H, B, groups, int(g.integers(1, 3))))
+    return cases
+
+
+@pytest.mark.parametrize("V,H,B,groups,cd", _random_cases())
+def test_random_shapes_match_oracle(V, H, B, groups, cd):
+    """Randomly drawn layer / batch sizes (fixed seed): aligned and unaligned rows, short and split-K visible
+    dimensions, batches of one to three 64-row chunks, optional softmax group; CD-k update + a mean-field chain."""
+    from imdbn import engine as E
+    r, st, g = _mk(V, H, groups, seed=V * 7 + H)
+    X = g.random((B, V), dtype=F32)
+    X[:, : V // 2] = (X[:, : V // 2] > 0.5)
+    Dz = groups[0][0] if groups else V // 3
+    vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+    vk[:, :Dz] = X[:, :Dz]; km[:, :Dz] = 1
+    with E.use_rng(E.PhiloxRng(seed=5)):
+        l = r.train_epoch(P.T(X, DEV), 3, 10, CD=cd)
+        a = r.noisy_meanfield_annealed(P.T(vk, DEV), P.T(km, DEV), n_steps=6)
+        f = r.free_energy(P.T(X, DEV))
+    ps = PhiloxStream(5)
+    lo = O.train_epoch(st, X, 3, cd, ps)
+    assert_close(float(l), lo, 1e-5, "loss")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
+    assert_close(P.N(a), O.noisy_meanfield_annealed(st, vk, km, ps, n_steps=6), 1e-4, "noisy mean-field chain", atol=2e-6)
+    assert_close(P.N(f), O.free_energy(st, X), 2e-5, "free energy")
+
+
 def test_products_are_fp32_exact():
     """bf16x3 split: v@W against float64 must be at fp32 rounding level (not bf16 level)."""
     r, st, g = _mk(2000, 300, None, seed=11)

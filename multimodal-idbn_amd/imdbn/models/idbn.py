@@ -15,6 +15,7 @@ from typing import List, Optional
 import torch
 
 from imdbn.models.rbm import RBM
+from imdbn.utils import batches
 
 
 class iDBN:
@@ -86,7 +87,7 @@ class iDBN:
         self.loss_history = []
         for epoch in range(int(epochs)):
             losses = []
-            for img, _ in self.dataloader:
+            for img, _ in batches(self.dataloader):
                 v = img.to(self.device).view(img.size(0), -1).float()
                 for rbm in self.layers:
                     loss = rbm.train_epoch(v, epoch, epochs, CD=self.cd_k)

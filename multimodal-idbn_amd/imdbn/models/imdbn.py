@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from imdbn import engine as _E
 from imdbn.models.idbn import iDBN
 from imdbn.models.rbm import RBM
+from imdbn.utils import batches
 
 WARMUP_Y_EPOCHS = 8          # imdbn.py:540
 Z_CLAMP_EVERY = 50           # imdbn.py:600
@@ -119,7 +120,7 @@ class iMDBN(nn.Module):
         sum_z, n = None, 0
         class_counts = torch.zeros(K, device=self.device)
         zs, ys = [], []
-        for b, (imgs, lbls) in enumerate(self.dataloader):
+        for b, (imgs, lbls) in enumerate(batches(self.dataloader)):
             if b >= n_batches:
                 break
             z = self.image_idbn.represent(imgs.to(self.device).view(imgs.size(0), -1).float())
@@ -197,7 +198,7 @@ class iMDBN(nn.Module):
         self.finetune_losses = []
         for ep in range(int(epochs)):
             losses = []
-            for img, _ in self.dataloader:
+            for img, _ in batches(self.dataloader):
                 v = img.to(self.device).view(img.size(0), -1).float()
                 for rbm in self.image_idbn.layers[:-1]:
                     v = rbm.forward(v)
@@ -302,7 +303,7 @@ class iMDBN(nn.Module):
             cd_losses = []
             acc = torch.zeros(5, device=self.device, dtype=torch.float64)   # n, top1, top3, ce_sum, mse_sum
             npix = None
-            for b_idx, (img, y) in enumerate(self.dataloader):
+            for b_idx, (img, y) in enumerate(batches(self.dataloader)):
                 img = img.to(self.device).view(img.size(0), -1).float()
                 y = y.to(self.device).float()
                 with torch.no_grad():

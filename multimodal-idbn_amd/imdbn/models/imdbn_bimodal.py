@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from imdbn.models.idbn import iDBN
 from imdbn.models.rbm import RBM
+from imdbn.utils import batches
 
 WARMUP_EPOCHS = 8            # imdbn_bimodal.py:736
 AUX_CD = 3                   # :762,:775,:800,:814  (clamped updates run CD-3 with sampled hidden units)
@@ -134,7 +135,7 @@ class iMDBN_BiModal(nn.Module):
     def init_joint_bias_from_data(self, n_batches: int = 10):
         sum_z1 = sum_z2 = None
         n = 0
-        for b, (mod1, mod2) in enumerate(self.dataloader):
+        for b, (mod1, mod2) in enumerate(batches(self.dataloader)):
             if b >= n_batches:
                 break
             z1 = self.mod1_dbn.represent(mod1.to(self.device).view(mod1.size(0), -1).float())
@@ -199,7 +200,7 @@ class iMDBN_BiModal(nn.Module):
         for epoch in range(int(epochs)):
             cd_losses = []
             acc = torch.zeros(3, device=self.device, dtype=torch.float64)      # n, mse_mod1_sum, mse_mod2_sum
-            for mod1, mod2 in self.dataloader:
+            for mod1, mod2 in batches(self.dataloader):
                 v1 = mod1.to(self.device).view(mod1.size(0), -1).float()
                 v2 = mod2.to(self.device).view(mod2.size(0), -1).float()
                 B = v1.size(0)

@@ -51,6 +51,23 @@ def test_live_best_of_k_host_logic():
     P.case_live_best_of_k("cpu")
 
 
+def test_batches_helper_is_the_dataloader():
+    """imdbn.utils.batches slices a sequential TensorDataset loader and defers to the DataLoader otherwise."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from imdbn.utils import batches
+    X = torch.arange(50.).view(25, 2); Y = torch.arange(25)
+    for kw in (dict(batch_size=8), dict(batch_size=8, drop_last=True), dict(batch_size=8, shuffle=True), dict(batch_size=5),
+               dict(batch_size=4, collate_fn=lambda b: b)):
+        dl = DataLoader(TensorDataset(X, Y), **kw)
+        torch.manual_seed(0); a = list(dl)
+        torch.manual_seed(0); b = list(batches(dl))
+        assert len(a) == len(b)
+        if "collate_fn" in kw:
+            continue
+        for p_, q_ in zip(a, b):
+            assert all(torch.equal(x, y) for x, y in zip(p_, q_)), kw
+
+
 def test_product_refuses_cpu_without_engine():
     """No silent CPU fallback: without the test double a CPU tensor must raise."""
     E.set_engine_for_testing(None)

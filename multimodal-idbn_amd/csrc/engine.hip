@@ -542,7 +542,7 @@ bool chain_kernel_ok(const Ctx& c, int n_steps) {
     if (g_no_chain_kernel || !L.k4_planes || n_steps < 2 || n_steps > CHAIN_MAX_STEPS) return false;
     if (c.d->n_groups > 1) return false;                   // the kernel keeps ONE softmax group's logits in LDS
     const int gw = c.d->n_groups ? c.d->group_end[0] - c.d->group_start[0] : 0;
-    const size_t lds = (size_t)c.rt * K4_ROWS * ((rup(L.V, 32) + 8) + (rup(L.H, 32) + 8)) * 2      // activation terms
+    const size_t lds = (size_t)(c.nw == 3 ? 2 : 1) * K4_ROWS * ((rup(L.V, 32) + 8) + (rup(L.H, 32) + 8)) * 2      // activation terms
                      + (size_t)K4_ROWS * (rup(std::max(L.V, L.H), 16) + 1) * 4                        // fp32 stage
                      + (size_t)K4_ROWS * (gw + 1) * 4 + K4_ROWS * 16;                                  // group logits, row stats
     return gw <= GROUP_WMAX && lds <= (size_t)K4_LDS_BYTES;
@@ -575,8 +575,11 @@ int run_chain_k4(Ctx& c, const float* vk, const float* mask, int64_t ldk, int n_
         }
         hipLaunchKernelGGL(chain_write_recs, dim3(1), dim3(64), 0, c.s, batch, L.chain_recs + t0, n);
     }
-    hipLaunchKernelGGL(k4_split_planes, dim3(std::max(cdiv(L.H, 16), cdiv(L.V, 16)), std::max(cdiv(L.V, 32), cdiv(L.H, 32)), 2), dim3(64), 0, c.s,
-                       d->W, d->ldw, L.V, L.H, c.nw, L.k4_planes, L.k4_plane_stride);
+    {
+        const dim3 sg(std::max(cdiv(L.H, 16), cdiv(L.V, 16)), std::max(cdiv(L.V, 32), cdiv(L.H, 32)), 2);
+        if (c.nw == 3) hipLaunchKernelGGL(k4_split_planes<2>, sg, dim3(64), 0, c.s, d->W, d->ldw, L.V, L.H, L.k4_planes, L.k4_plane_stride);
+        else           hipLaunchKernelGGL(k4_split_planes<1>, sg, dim3(64), 0, c.s, d->W, d->ldw, L.V, L.H, L.k4_planes, L.k4_plane_stride);
+    }
     K4Args a;
     memset(&a, 0, sizeof(a));
     a.planes = L.k4_planes; a.plane_stride = L.k4_plane_stride;
@@ -592,7 +595,7 @@ int run_chain_k4(Ctx& c, const float* vk, const float* mask, int64_t ldk, int n_
     // rows per block: enough blocks to spread the per-element work (Philox, Box-Muller, sigmoid) over the CUs;
     // one block per CU at most (every block streams all of W from L2)
     a.rows = g_k4_rows > 0 ? g_k4_rows : (B <= 2 * cu_count() ? 2 : (B <= 4 * cu_count() ? 4 : (B <= 8 * cu_count() ? 8 : 16)));      // measured: 0.90 / 0.99 / 1.19 / 1.59 ms for 2 / 4 / 8 / 16 rows (30 steps, 532<->256)
-    if (c.nw == 3) hipLaunchKernelGGL(k4_chain<3>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);
+    if (c.nw == 3) hipLaunchKernelGGL(k4_chain<2>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);      // PARITY: fp16 hi + lo terms
     else           hipLaunchKernelGGL(k4_chain<1>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);
     HIPCHK(hipGetLastError());
     // operand forms of the final state (what the last v|h launch of the per-launch path leaves behind)

@@ -5,10 +5,10 @@
 // small RBM (532 <-> 256).  As one launch per half step they are pure launch / kernel-boundary latency (~49 us per
 // step), and a grid-wide barrier costs as much as a launch on this part.  But batch rows never
 // interact inside a chain, so here a block owns a few batch rows and runs the WHOLE chain for them:
-//   * W is split once per call into bf16 hi/mid/lo planes in MFMA-fragment order for both directions
+//   * W is split once per call into fp16 hi/lo planes (k4_terms) in MFMA-fragment order for both directions
 //     (k4_split_planes: plane[dir][term][n-tile][k-block] = one contiguous KB = one wave load);
-//   * the visible / hidden activations of its rows live in LDS as bf16 terms (exact for fp32 values);
-//   * every half step streams the planes from L2 through v_mfma_f32_16x16x32_bf16 (8 waves split the 16-column
+//   * the visible / hidden activations of its rows live in LDS as the same two fp16 terms;
+//   * every half step streams the planes from L2 through v_mfma_f32_16x16x32_f16 (8 waves split the 16-column
 //     output tiles behind a 6-deep register ring; measured at the L2->CU fill rate, ~117 GB/s), stages the raw sums
 //     in LDS and applies the same epilogue arithmetic as kernels_ew.hpp finish_rows / finish_groups, one element
 //     per thread;
@@ -23,6 +23,30 @@
 namespace imdbn {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// Term encodings of the chain kernel (template argument NW = number of terms):
+//   NW == 2: hi + lo fp16 (11 + 11 significand bits; 4 bytes per weight and 4 MFMAs per product instead of 6 and 9
+//            for the three bf16 terms of the propagation kernels -- the chain kernel is bound by the bytes a CU
+//            streams; the ~2^-22 relative representation error is far below the 1e-4 parity budget and the
+//            fixtures' Bernoulli margins) -- PARITY mode;
+//   NW == 1: one bf16 (FAST mode, as everywhere else).
+template <int NW>
+__device__ __forceinline__ void k4_terms(float x, uint32_t (&t)[2]) {
+    if constexpr (NW == 2) {
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        t[0] = (uint32_t)__builtin_bit_cast(unsigned short, hi);
+        t[1] = (uint32_t)__builtin_bit_cast(unsigned short, lo);
+    } else {
+        t[0] = bf16_rne(x); t[1] = 0u;
+    }
+}
+template <int NW>
+__device__ __forceinline__ f32x4 k4_mfma(const uint4& a, const uint4& b, const f32x4& c) {
+    if constexpr (NW == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else                   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), as_frag(b), c, 0, 0, 0);
+}
 
 struct ChainDraw { const float* tape; uint64_t draw; };
 struct ChainRec {                 // one chain step (imdbn_chain_step + the draw cursors the host assigned to it)
@@ -46,24 +70,27 @@ __global__ void chain_write_recs(const ChainRecBatch b, ChainRec* dst, int n) {
 // plane[dir][term]: NT x KB fragments of 64 lanes x 8 bf16.  dir 0 (h|v): n = hidden unit, k = visible unit;
 // dir 1 (v|h): n = visible unit, k = hidden unit.  Lane l of fragment (nt, kb) holds k = 32*kb + 8*(l>>4) + j,
 // n = 16*nt + (l&15): the B operand of v_mfma_f32_16x16x32_bf16.
-__global__ __launch_bounds__(64) void k4_split_planes(const float* __restrict__ W, int64_t ldw, int V, int H, int nw,
+template <int NW>
+__global__ __launch_bounds__(64) void k4_split_planes(const float* __restrict__ W, int64_t ldw, int V, int H,
                                                       bf16_t* __restrict__ planes, int64_t plane_stride) {
     const int l = threadIdx.x, dir = blockIdx.z;
     const int NT = dir == 0 ? (H + 15) / 16 : (V + 15) / 16, KB = dir == 0 ? (V + 31) / 32 : (H + 31) / 32;
     const int nt = blockIdx.x, kb = blockIdx.y;
     if (nt >= NT || kb >= KB) return;
     const int n = 16 * nt + (l & 15), k0 = 32 * kb + 8 * (l >> 4);
-    uint32_t t[3][8];
+    uint32_t t[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = k0 + j;
         float x = 0.f;
         if (dir == 0) { if (k < V && n < H) x = W[(int64_t)k * ldw + n]; }
         else          { if (n < V && k < H) x = W[(int64_t)n * ldw + k]; }
-        if (nw == 3) split3(x, t[0][j], t[1][j], t[2][j]);
-        else { t[0][j] = bf16_rne(x); t[1][j] = 0u; t[2][j] = 0u; }
+        uint32_t tt[2];
+        k4_terms<NW>(x, tt);
+        t[0][j] = tt[0]; t[1][j] = tt[1];
     }
-    for (int tw = 0; tw < nw; ++tw) {
+#pragma unroll
+    for (int tw = 0; tw < NW; ++tw) {
         bf16_t* q = planes + (dir * 3 + tw) * plane_stride + ((int64_t)(nt * KB + kb) * 64 + l) * 8;
         *reinterpret_cast<uint4*>(q) = make_uint4(t[tw][0] | (t[tw][1] << 16), t[tw][2] | (t[tw][3] << 16),
                                                   t[tw][4] | (t[tw][5] << 16), t[tw][6] | (t[tw][7] << 16));
@@ -89,16 +116,13 @@ __device__ __forceinline__ DrawSrc k4_src(const K4Args& a, const ChainDraw& d, i
     return s;
 }
 
-// value -> bf16 terms at act[t][row][col] (row pitch AK elements)
-__device__ __forceinline__ void k4_put(bf16_t* act, int AK, int terms, int row, int col, float x, bool exact1) {
-    if (exact1 || terms == 1) {
-        act[row * AK + col] = (bf16_t)bf16_rne(x);
-        if (terms == 3) { act[(K4_ROWS + row) * AK + col] = 0; act[(2 * K4_ROWS + row) * AK + col] = 0; }
-    } else {
-        uint32_t hi, mid, lo;
-        split3(x, hi, mid, lo);
-        act[row * AK + col] = (bf16_t)hi; act[(K4_ROWS + row) * AK + col] = (bf16_t)mid; act[(2 * K4_ROWS + row) * AK + col] = (bf16_t)lo;
-    }
+// value -> its NW terms at act[t][row][col] (row pitch AK elements); exact1: the value is 0 or 1 (one term is exact)
+template <int NW>
+__device__ __forceinline__ void k4_put(bf16_t* act, int AK, int row, int col, float x, bool exact1) {
+    uint32_t t[2];
+    k4_terms<NW>(x, t);
+    act[row * AK + col] = (bf16_t)t[0];
+    if constexpr (NW == 2) act[(K4_ROWS + row) * AK + col] = exact1 ? (bf16_t)0 : (bf16_t)t[1];
 }
 
 // stage[16][SP] = act[16 x K] * plane[K x N].  Wave w owns the 16-column tiles w, w+16, ...; its (tile, k-block)
@@ -143,7 +167,7 @@ __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB
                 const uint4 af = *reinterpret_cast<const uint4*>(act + (ta * K4_ROWS + (l & 15)) * AK + 32 * min(kb, KB - 1) + 8 * (l >> 4));
 #pragma unroll
                 for (int tw = 0; tw < NW; ++tw)
-                    acc[tw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(ring[d][tw]), acc[tw], 0, 0, 0);
+                    acc[tw] = k4_mfma<NW>(af, ring[d][tw], acc[tw]);
             }
             __builtin_amdgcn_sched_barrier(0);
             load(ring[d], it0 + d + K4_RING);
@@ -165,7 +189,7 @@ __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB
     }
 }
 
-template <int NW>          // weight terms = terms of a real-valued activation (PARITY 3, FAST 1)
+template <int NW>          // terms of the weights and of a real-valued activation: 2 (fp16 hi + lo, PARITY) or 1 (bf16, FAST)
 __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     __shared__ __attribute__((aligned(16))) char smem[K4_LDS_BYTES];
     const int tid = threadIdx.x;
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     for (int i = tid; i < K4_ROWS * (VK - 8); i += K4_THREADS) {
         const int row = i / (VK - 8), col = i - row * (VK - 8);
         const float x = (col < a.V && row < RB && b0 + row < a.B) ? a.state[(int64_t)(b0 + row) * a.lds + col] : 0.f;
-        k4_put(vact, VK, at, row, col, x, false);
+        k4_put<NW>(vact, VK, row, col, x, false);
     }
     for (int i = tid; i < at * K4_ROWS * HK; i += K4_THREADS) hact[i] = 0;          // pad columns and rows >= RB stay zero for the whole chain
     __syncthreads();
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                 if (r.sigma > 0.f) x = x + draw_normal(nz, bd, col) * r.sigma;
                 float p = sigmoidf_ref(x);
                 if (sample_h) p = (p > draw_uniform(un, bd, col)) ? 1.f : 0.f;
-                k4_put(hact, HK, at, row, col, (b0 + row < a.B) ? p : 0.f, sample_h);
+                k4_put<NW>(hact, HK, row, col, (b0 + row < a.B) ? p : 0.f, sample_h);
             }
         }
         __syncthreads();
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                     else v = (mixed > u) ? 1.f : 0.f;
                 }
                 if (b >= a.B) v = 0.f;
-                k4_put(vact, VK, at, row, col, v, false);
+                k4_put<NW>(vact, VK, row, col, v, false);
                 if (last && b < a.B) a.state[(int64_t)b * a.lds + col] = v;
             }
         }
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                 else if (vmode == 1) { const float o = (j == idx) ? 1.f : 0.f; v = clamp ? (o * (1.0f - m) + kn * m) : o; }
                 else v = (j == idx) ? 1.f : 0.f;
                 if (b >= a.B) v = 0.f;
-                k4_put(vact, VK, at, row, col, v, false);
+                k4_put<NW>(vact, VK, row, col, v, false);
                 if (last && b < a.B) a.state[(int64_t)b * a.lds + col] = v;
             }
         }

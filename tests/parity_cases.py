@@ -343,3 +343,24 @@ def case_bimodal_small(dev, rel=3e-4):
     h = mdl.joint_history[-1]
     assert h["mod1_mse"] is not None and 0.0 < h["mod1_mse"] < 1.0 and 0.0 < h["mod2_mse"] < 1.0
     return mdl
+
+
+def case_class_free_energies(dev, V=150, Dz=140, H=48, B=21, rel=2e-5):
+    """imdbn.utils.energy_utils against the reference formula (energy_utils.py:31-56) evaluated with the oracle."""
+    import oracle.rbm_oracle as O
+    from oracle.draws import DrawStream
+    from imdbn.utils import class_free_energies, rbm_free_energy
+    K = V - Dz
+    s = DrawStream(11)
+    W0 = (s.normal((V, H)) / F32(np.sqrt(V))).astype(F32)
+    hb = (s.normal((H,)) * F32(0.1)).astype(F32); vb = (s.normal((V,)) * F32(0.1)).astype(F32)
+    r = RBM(V, H, 0.1, 1e-4, 0.5, softmax_groups=[(Dz, V)])
+    set_params(r, dev, W0, hb, vb)
+    st = O.RBMState.create(W0, 0.1, 1e-4, 0.5, softmax_groups=[(Dz, V)], hid_bias=hb, vis_bias=vb)
+    z = s.uniform((B, Dz)).astype(F32)
+    got = N(class_free_energies(r, T(z, dev), K, Dz))
+    want = np.stack([O.free_energy(st, np.concatenate([z, np.tile(np.eye(K, dtype=F32)[k], (B, 1))], 1)) for k in range(K)], 1)
+    assert got.shape == (B, K)
+    assert_close(got, want, rel, "class free energies")
+    v = np.concatenate([z, np.eye(K, dtype=F32)[np.arange(B) % K]], 1)
+    assert_close(N(rbm_free_energy(r, T(v, dev))), O.free_energy(st, v), rel, "rbm_free_energy")

@@ -51,6 +51,10 @@ def test_live_best_of_k_host_logic():
     P.case_live_best_of_k("cpu")
 
 
+def test_energy_utils_host_logic():
+    P.case_class_free_energies("cpu")
+
+
 def test_batches_helper_is_the_dataloader():
     """imdbn.utils.batches slices a sequential TensorDataset loader and defers to the DataLoader otherwise."""
     from torch.utils.data import DataLoader, TensorDataset

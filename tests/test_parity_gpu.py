@@ -167,6 +167,11 @@ def test_free_energy_matches_oracle(V, H, B):
     assert_close(P.N(r.free_energy(P.T(v, DEV))), O.free_energy(st, v), 1e-5, "free energy")
 
 
+def test_class_free_energies_gpu():
+    P.case_class_free_energies(DEV)
+    P.case_class_free_energies(DEV, V=532, Dz=500, H=256, B=64)        # 2048 stacked rows: several batch chunks
+
+
 def test_live_best_of_k_gpu():
     en = P.case_live_best_of_k(DEV, K=16)
     assert en.shape[0] == 16

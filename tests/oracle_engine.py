@@ -134,6 +134,22 @@ class OracleEngine:
         p[o + 2 * H + V] = x["sq_err"].sum(dtype=F32)
         return self._t(p)
 
+    # ---- factor exchange (host-logic stand-in: a rank's "factor block" is its packed statistics as bytes) ----
+    def factor_mode_ok(self, rbm, B) -> bool:
+        return 1 <= B <= 64 and not (getattr(rbm, "softmax_groups", None) or [])
+
+    def cd_factors(self, rbm, data, cd_k, rng):
+        return self.cd_stats(rbm, data, cd_k, rng).contiguous().view(torch.uint8)
+
+    def gather_buffer(self, rbm, B, world):
+        V, H = rbm.W.shape
+        return torch.empty(world, 4 * self.packed_floats(V, H), dtype=torch.uint8)
+
+    def apply_factors(self, rbm, gathered, rows_per_rank, global_B, lr, mom):
+        assert gathered.dtype == torch.uint8 and gathered.dim() == 2
+        packed = gathered.view(torch.float32).sum(0)
+        return self.apply_delta(rbm, packed, global_B, lr, mom)
+
     def apply_delta(self, rbm, packed, global_B, lr, mom):
         st = self._state(rbm, True)
         V, H = st.W.shape

@@ -18,19 +18,19 @@ PKG = os.path.join(ROOT, "multimodal-idbn_amd")
 V, H, B, SEED, STEPS = 96, 40, 16, 77, 3
 
 
-def _make(rank_tag=""):
+def _make(groups=True):
     from imdbn.models import RBM
     g = np.random.Generator(np.random.PCG64(5))
     W0 = (g.standard_normal((V, H), dtype=np.float32) / np.float32(np.sqrt(V))).astype(np.float32)
     X = (g.random((STEPS, B, V), dtype=np.float32) > 0.6).astype(np.float32)
     r = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, sparsity=True, sparsity_factor=0.1,
-            softmax_groups=[(88, 96)]).to("cpu")
+            softmax_groups=[(88, 96)] if groups else None).to("cpu")
     r.W.data = torch.from_numpy(W0.copy())
     r.W_m, r.hb_m, r.vb_m = torch.zeros_like(r.W.data), torch.zeros_like(r.hid_bias.data), torch.zeros_like(r.vis_bias.data)
     return r, X
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="allreduce"):
     for p in (ROOT, PKG, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -41,9 +41,9 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     E.set_engine_for_testing(OracleEngine())
-    E.dp.enable()
-    assert E.dp.active() and E.dp.world_size() == world and E.dp.rank() == rank
-    r, X = _make()
+    E.dp.enable(mode=mode)
+    assert E.dp.active() and E.dp.world_size() == world and E.dp.rank() == rank and E.dp.mode() == mode
+    r, X = _make(groups=(mode == "allreduce"))
     E.set_rng(E.PhiloxRng(SEED))
     per = B // world
     losses = []
@@ -55,7 +55,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_update_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("mode", ["allreduce", "factors"])
+def test_two_rank_update_equals_single_rank(tmp_path, mode):
+    """mode "factors": the all-gather exchange of per-rank blocks (the test double's block is its packed statistics;
+    the real factor block is exercised on the GPU by test_factor_exchange_*)."""
     import socket
     import torch.multiprocessing as mp
     from imdbn import engine as E
@@ -64,12 +67,12 @@ def test_two_rank_update_equals_single_rank(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, PKG, HERE, os.environ.get("PYTHONPATH", "")])
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
 
     # single-rank reference on the full global batch, same seed
     E.set_engine_for_testing(OracleEngine())
     try:
-        r, X = _make()
+        r, X = _make(groups=(mode == "allreduce"))
         ref_losses = []
         with E.use_rng(E.PhiloxRng(SEED)):
             for s in range(STEPS):

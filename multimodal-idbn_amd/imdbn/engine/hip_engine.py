@@ -7,6 +7,7 @@ scratch workspaces keyed on (device, V, H, B).
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -37,6 +38,10 @@ class HipEngine:
         self._lib = N.lib()
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.mode = N.PARITY_F32
+        # tuning / A-B aid: IMDBN_OPTS="name=value,..." -> imdbn_set_option (include/imdbn_engine.h)
+        for kv in filter(None, os.environ.get("IMDBN_OPTS", "").split(",")):
+            k, _, v = kv.partition("=")
+            self.set_option(k.strip(), int(v or 1))
 
     # ---- plumbing -----------------------------------------------------------------------------
     def device_info(self):

@@ -202,6 +202,15 @@ int imdbn_rbm_clamped_step(const imdbn_rbm_desc* d, const float* v_known, const 
                            const imdbn_cd_opts* o, imdbn_rng* rng, float* loss_out,
                            void* ws, size_t ws_bytes, imdbn_stream_t stream);
 
+/* data-parallel half of the clamped update (reference statistics rbm.py:455-472): this rank's
+ * un-normalised statistics in the packed layout of imdbn_rbm_cd_stats -> all-reduce (sum) ->
+ * imdbn_rbm_apply_delta with o->sparsity = 0 (the clamped update has no sparsity term, rbm.py:473-481). */
+int imdbn_rbm_clamped_stats(const imdbn_rbm_desc* d, const float* v_known, const float* mask, int64_t ldk, int B,
+                            int n_init, const imdbn_chain_step* init_steps,
+                            const float* mu, int64_t ldmu, int Dz,
+                            const imdbn_cd_opts* o, imdbn_rng* rng, float* packed,
+                            void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

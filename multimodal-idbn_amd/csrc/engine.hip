@@ -857,6 +857,19 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
     return 0;
 }
 
+// bias / sparsity / error tail of the packed statistics buffer (after the V*H delta-W floats)
+static int launch_pack(Ctx& c, float* packed) {
+    const imdbn_rbm_desc* d = c.d;
+    PackArgs p;
+    memset(&p, 0, sizeof(p));
+    p.tail = packed + (size_t)d->V * d->H; p.H = d->H; p.V = d->V;
+    p.hpos = c.L.cs_hpos; p.hneg = c.L.cs_hneg; p.vpos = c.L.cs_vpos; p.vneg = c.L.cs_vneg; p.P = c.L.P;
+    p.loss_part = c.L.loss_part; p.n_loss = n_loss_used(c, false);
+    hipLaunchKernelGGL(pack_stats, dim3(cdiv(std::max(d->V, d->H), 256) + 1), dim3(256), 0, c.s, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 size_t imdbn_packed_delta_floats(int V, int H) {
     const size_t n = (size_t)V * H + (size_t)2 * H + V + 1;
     return (n + 3) / 4 * 4;
@@ -871,13 +884,7 @@ int imdbn_rbm_cd_stats(const imdbn_rbm_desc* d, const float* data, int64_t ldd, 
     CHK(cd_phases(c, data, ldd, o));
     CHK(c.rng.finish());
     CHK(launch_assoc(c, 1, o, c.nw == 1 ? 1 : 0, c.L.flags, 1, 1.0f, packed));
-    PackArgs p;
-    memset(&p, 0, sizeof(p));
-    p.tail = packed + (size_t)d->V * d->H; p.H = d->H; p.V = d->V;
-    p.hpos = c.L.cs_hpos; p.hneg = c.L.cs_hneg; p.vpos = c.L.cs_vpos; p.vneg = c.L.cs_vneg; p.P = c.L.P;
-    p.loss_part = c.L.loss_part; p.n_loss = n_loss_used(c, false);
-    hipLaunchKernelGGL(pack_stats, dim3(cdiv(std::max(d->V, d->H), 256) + 1), dim3(256), 0, c.s, p);
-    HIPCHK(hipGetLastError());
+    CHK(launch_pack(c, packed));
     return 0;
 }
 
@@ -1006,15 +1013,12 @@ int imdbn_rbm_chain(const imdbn_rbm_desc* d, const float* v_known, const float* 
     return c.rng.finish();
 }
 
-int imdbn_rbm_clamped_step(const imdbn_rbm_desc* d, const float* v_known, const float* mask, int64_t ldk, int B,
-                           int n_init, const imdbn_chain_step* init_steps, const float* mu, int64_t ldmu, int Dz,
-                           const imdbn_cd_opts* o, imdbn_rng* rng, float* loss_out, void* ws, size_t ws_bytes,
-                           imdbn_stream_t stream) {
-    CHK(check_desc(d, true));
-    if (!v_known || !mask || !o || ldk < d->V) return fail(IMDBN_E_INVALID, "clamped_step: bad argument");
-    if (o->cd_k < 1) return fail(IMDBN_E_INVALID, "CD=%d", o->cd_k);
-    Ctx c(d, rng, S(stream));
-    CHK(setup(c, B, ws, ws_bytes));
+// rbm.py:443-471: v+ by conditional inference, H+, CD-k from v+ (optionally re-clamped / sampled), H-.
+// Leaves the statistics operands in the workspace exactly as cd_phases does.
+static int clamped_phases(Ctx& c, const float* v_known, const float* mask, int64_t ldk, int n_init,
+                          const imdbn_chain_step* init_steps, const float* mu, int64_t ldmu, int Dz, const imdbn_cd_opts* o) {
+    const imdbn_rbm_desc* d = c.d;
+    const int B = c.L.B;
     const Layout& L = c.L;
     float* vplus = L.f_v[0];
     // positive phase: v+ by conditional inference (rbm.py:443-453), H+ = up(v+) (:455)
@@ -1052,9 +1056,41 @@ int imdbn_rbm_clamped_step(const imdbn_rbm_desc* d, const float* v_known, const 
         f.colsum_part = L.cs_hneg; f.colsum_src = 1;
         CHK(prop(c, true, OpIn{L.vis_rm[1], o->sample_v ? 1 : c.rt, nullptr}, f));
     }
+    return 0;
+}
+
+int imdbn_rbm_clamped_step(const imdbn_rbm_desc* d, const float* v_known, const float* mask, int64_t ldk, int B,
+                           int n_init, const imdbn_chain_step* init_steps, const float* mu, int64_t ldmu, int Dz,
+                           const imdbn_cd_opts* o, imdbn_rng* rng, float* loss_out, void* ws, size_t ws_bytes,
+                           imdbn_stream_t stream) {
+    CHK(check_desc(d, true));
+    if (!v_known || !mask || !o || ldk < d->V) return fail(IMDBN_E_INVALID, "clamped_step: bad argument");
+    if (o->cd_k < 1) return fail(IMDBN_E_INVALID, "CD=%d", o->cd_k);
+    Ctx c(d, rng, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    CHK(clamped_phases(c, v_known, mask, ldk, n_init, init_steps, mu, ldmu, Dz, o));
     CHK(c.rng.finish());
     const BiasArgs bias = make_bias(c, o, false, (float)B, loss_out);
     CHK(launch_assoc(c, 0, o, c.rt, nullptr, o->sample_v ? 1 : c.rt, (float)B, nullptr, &bias));
+    return 0;
+}
+
+// data-parallel half of the clamped update ("train_epoch_clamped shards the same way"): the rank's
+// un-normalised statistics in the packed layout of imdbn_rbm_cd_stats; all-reduce, then imdbn_rbm_apply_delta
+// (with sparsity off: the clamped update has no sparsity term, rbm.py:473-481).
+int imdbn_rbm_clamped_stats(const imdbn_rbm_desc* d, const float* v_known, const float* mask, int64_t ldk, int B,
+                            int n_init, const imdbn_chain_step* init_steps, const float* mu, int64_t ldmu, int Dz,
+                            const imdbn_cd_opts* o, imdbn_rng* rng, float* packed, void* ws, size_t ws_bytes,
+                            imdbn_stream_t stream) {
+    CHK(check_desc(d, false));
+    if (!v_known || !mask || !o || !packed || ldk < d->V) return fail(IMDBN_E_INVALID, "clamped_stats: bad argument");
+    if (o->cd_k < 1) return fail(IMDBN_E_INVALID, "CD=%d", o->cd_k);
+    Ctx c(d, rng, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    CHK(clamped_phases(c, v_known, mask, ldk, n_init, init_steps, mu, ldmu, Dz, o));
+    CHK(c.rng.finish());
+    CHK(launch_assoc(c, 1, o, c.rt, nullptr, o->sample_v ? 1 : c.rt, 1.0f, packed));
+    CHK(launch_pack(c, packed));
     return 0;
 }
 

@@ -327,10 +327,10 @@ class HipEngine:
                 "imdbn_rbm_apply_factors")
         return loss.reshape(())
 
-    def apply_delta(self, rbm, packed, global_B, lr, mom):
+    def apply_delta(self, rbm, packed, global_B, lr, mom, sparsity: Optional[bool] = None):
         d = self._desc(rbm, True)
         dev = packed.device
-        o = self._opts(rbm, lr, mom, 1, sparsity=getattr(rbm, "sparsity", False))
+        o = self._opts(rbm, lr, mom, 1, sparsity=getattr(rbm, "sparsity", False) if sparsity is None else sparsity)
         loss = torch.empty(1, device=dev)
         N.check(self._lib.imdbn_rbm_apply_delta(C.byref(d), _ptr(packed), int(global_B), C.byref(o), _ptr(loss),
                                                  self._stream(dev)), "imdbn_rbm_apply_delta")
@@ -375,3 +375,26 @@ class HipEngine:
                 "imdbn_rbm_clamped_step")
         self._done(rng, r, sched)
         return loss.reshape(())
+
+    def clamped_stats(self, rbm, v_known, mask, init_steps: List[dict], mu, cd_k, sample_h, sample_v, reclamp, rng,
+                      out: Optional[torch.Tensor] = None):
+        """Data-parallel half of clamped_step: the shard's packed statistics (apply with apply_delta(sparsity=False))."""
+        d = self._desc(rbm, False)
+        vk, km = _f32c(v_known, "v_known"), _f32c(mask, "mask")
+        if vk.stride(0) != km.stride(0):
+            vk, km = vk.contiguous(), km.contiguous()
+        B, dev = vk.size(0), vk.device
+        o = self._opts(rbm, 0.0, 0.0, cd_k, sparsity=False, sample_h=sample_h, sample_v=sample_v, reclamp=reclamp)
+        sched = R.sched_clamped(d.V, d.H, self._groups(rbm), init_steps, cd_k, sample_h, sample_v)
+        r, keep = self._rng(rng, sched, B, dev)
+        mu_t = _f32c(mu, "mu") if mu is not None else None
+        packed = out if out is not None else torch.zeros(self.packed_floats(d.V, d.H), device=dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_clamped_stats(C.byref(d), _ptr(vk), _ptr(km), vk.stride(0), B, len(init_steps),
+                                                   self._steps(init_steps), _ptr(mu_t),
+                                                   mu_t.stride(0) if mu_t is not None else 0,
+                                                   mu_t.size(1) if mu_t is not None else 0, C.byref(o), C.byref(r),
+                                                   _ptr(packed), _ptr(ws), ws.numel(), self._stream(dev)),
+                "imdbn_rbm_clamped_stats")
+        self._done(rng, r, sched)
+        return packed

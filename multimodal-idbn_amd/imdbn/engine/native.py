@@ -81,6 +81,8 @@ SIGNATURES = {
                                C.POINTER(Rng), _P, _I64, _P, _SZ, _P]),
     "imdbn_rbm_clamped_step": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
                                       C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
+    "imdbn_rbm_clamped_stats": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
+                                      C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
 }
 
 _lib = None

@@ -129,25 +129,34 @@ class iMDBN(nn.Module):
             class_counts += lbls.to(self.device).float().sum(0)
             zs.append(z)
             ys.append(lbls.to(self.device).argmax(dim=1))
+        # per-class sums (:263-284); the reference's second pass recomputes the same represent()
+        z_class_sum = torch.zeros(K, Dz, device=self.device)
+        z_class_count = torch.zeros(K, device=self.device)
+        for z, y_idx in zip(zs, ys):
+            present = torch.bincount(y_idx, minlength=K)[:K].cpu()          # one sync per batch instead of K
+            for k in range(K):
+                if int(present[k]) > 0:
+                    m = (y_idx == k)
+                    z_class_sum[k] += z[m].sum(0)                           # the reference's summation order
+                    z_class_count[k] += m.sum()
+        if _E.dp.active():
+            # every rank saw its own shard of the first batches: the counters are sums over rows
+            pack = torch.cat([(sum_z if sum_z is not None else torch.zeros(Dz, device=self.device)).double(),
+                              torch.tensor([float(n)], device=self.device, dtype=torch.float64),
+                              class_counts.double(), z_class_sum.reshape(-1).double(), z_class_count.double()])
+            _E.dp.all_reduce_sum(pack)
+            sum_z, n = pack[:Dz].float(), int(round(float(pack[Dz])))
+            class_counts = pack[Dz + 1:Dz + 1 + K].float()
+            z_class_sum = pack[Dz + 1 + K:Dz + 1 + K + K * Dz].float().reshape(K, Dz)
+            z_class_count = pack[Dz + 1 + K + K * Dz:].float()
         if n == 0:
             return
         mean_z = (sum_z / n).clamp(1e-4, 1 - 1e-4)                                  # :256
         priors = class_counts / max(1, class_counts.sum())                          # :257
         priors = (priors + 1e-6) / (priors.sum() + 1e-6 * K)                        # :258
-        # per-class means (:263-284); the reference's second pass recomputes the same represent()
-        self.z_class_mean = torch.zeros(K, Dz, device=self.device)
-        self.z_class_count = torch.zeros(K, device=self.device)
-        for z, y_idx in zip(zs, ys):
-            for k in range(K):
-                m = (y_idx == k)
-                if m.any():
-                    self.z_class_mean[k] += z[m].sum(0)
-                    self.z_class_count[k] += m.sum()
-        for k in range(K):
-            if self.z_class_count[k] > 0:
-                self.z_class_mean[k] /= self.z_class_count[k]
-            else:
-                self.z_class_mean[k] = mean_z.clone()
+        seen = (z_class_count > 0).unsqueeze(1)
+        self.z_class_mean = torch.where(seen, z_class_sum / z_class_count.clamp_min(1.0).unsqueeze(1), mean_z.unsqueeze(0))
+        self.z_class_count = z_class_count
         self.joint_rbm.vis_bias.data[:Dz] = torch.log(mean_z) - torch.log1p(-mean_z)   # :291
         self.joint_rbm.vis_bias.data[Dz:Dz + K] = torch.log(priors)                    # :292
 
@@ -344,6 +353,8 @@ class iMDBN(nn.Module):
                                         (pred == gt).sum().double(),
                                         (topk_idx == gt.unsqueeze(1)).any(dim=1).sum().double(),
                                         ce.double(), mse.double()])
+            if _E.dp.active():                      # each rank accumulated its shard: sums over rows
+                _E.dp.all_reduce_sum(acc)
             a = acc.cpu()
             n = max(1.0, float(a[0]))
             rec = {"epoch": epoch, "n": int(a[0]), "text_top1": float(a[1]) / n, "text_top3": float(a[2]) / n,

@@ -125,7 +125,7 @@ class RBM(nn.Module):
     @torch.no_grad()
     def sample_visible(self, v_prob: torch.Tensor) -> torch.Tensor:
         """Bernoulli over all columns, one categorical per softmax group (rbm.py:125-135)."""
-        return self._eng().sample_visible(self, self._in(v_prob), _E.get_rng())
+        return self._eng().sample_visible(self, self._in(v_prob), self._rng(v_prob.size(0)))
 
     @torch.no_grad()
     def backward(self, h: torch.Tensor, return_logits: bool = False) -> torch.Tensor:
@@ -142,7 +142,15 @@ class RBM(nn.Module):
     @torch.no_grad()
     def gibbs_step(self, v: torch.Tensor, sample_h: bool = True, sample_v: bool = True):
         """One v -> h -> v' step; returns (v_next, v_prob, h, h_prob)   (rbm.py:174-178)."""
-        return self._eng().gibbs_step(self, self._in(v), sample_h, sample_v, _E.get_rng())
+        return self._eng().gibbs_step(self, self._in(v), sample_h, sample_v, self._rng(v.size(0)))
+
+    def _rng(self, B: int):
+        """The ambient draw source; under data parallelism Philox draws are keyed on the GLOBAL batch row
+        (rank r owns rows [r*B, (r+1)*B)), so a sharded call equals the unsharded one."""
+        rng = _E.get_rng()
+        if _E.dp.active() and isinstance(rng, _E.PhiloxRng):
+            rng.row0 = _E.dp.rank() * int(B)
+        return rng
 
     # ---- CD-k update (rbm.py:180-227) -----------------------------------------------------------
     @torch.no_grad()
@@ -155,12 +163,11 @@ class RBM(nn.Module):
         (SURVEY.md 8e).
         """
         lr, mom = self._lr_mom(epoch)
-        eng, rng, x = self._eng(), _E.get_rng(), self._in(data)
+        eng, x = self._eng(), self._in(data)
+        rng = self._rng(x.size(0))
         dp = _E.dp
         if dp.active():
             B = x.size(0)
-            if isinstance(rng, _E.PhiloxRng):
-                rng.row0 = dp.rank() * B
             if dp.mode() == "factors" and hasattr(eng, "factor_mode_ok") and eng.factor_mode_ok(self, B):
                 # exchange the factors (~7 MB per rank at 10000 x 1500) instead of the fp32 statistics (60 MB)
                 block = eng.cd_factors(self, x, CD, rng)
@@ -219,7 +226,7 @@ class RBM(nn.Module):
             steps.append(_step(T=Tt, sample_h=(t < hot), vmode=1 if sv else 0, clamp=True))
         if final_meanfield:
             steps.append(_step(T=1.0, clamp=True))
-        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, _E.get_rng())
+        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, self._rng(v_known.size(0)))
 
     @torch.no_grad()
     def noisy_meanfield_annealed(
@@ -237,7 +244,7 @@ class RBM(nn.Module):
         """rbm.py:332-367 (``hot_frac`` is accepted and, as in the reference, has no effect)."""
         mu, eta0 = self._mu()
         steps = self._nmf_steps(n_steps, T0, T1, sigma0, sharpen_last, T_cold_plus, eta0 if mu is not None else 0.0)
-        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, _E.get_rng(), mu=mu)
+        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, self._rng(v_known.size(0)), mu=mu)
 
     @torch.no_grad()
     def conditional_gibbs(
@@ -251,7 +258,7 @@ class RBM(nn.Module):
         """rbm.py:391-400; the last entry is the reference's final UN-clamped pass (:400)."""
         steps = [_step(sample_h=sample_h, vmode=1 if sample_v else 0, clamp=True) for _ in range(int(n_steps))]
         steps.append(_step(clamp=False))
-        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, _E.get_rng())
+        return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, self._rng(v_known.size(0)))
 
     # ---- clamped CD (rbm.py:402-483) -------------------------------------------------------------
     @torch.no_grad()
@@ -278,5 +285,14 @@ class RBM(nn.Module):
         else:                                                                       # rbm.py:450-453
             init = [_step(sample_h=sample_h, vmode=1 if sample_v else 0, clamp=True) for _ in range(int(cond_init_steps))]
             init.append(_step(clamp=False))
-        return self._eng().clamped_step(self, self._in(v_known), self._in(known_mask), init, mu,
-                                        aux_lr_mult * lr, mom, CD, sample_h, sample_v, reclamp_negative, _E.get_rng())
+        eng, vk, km = self._eng(), self._in(v_known), self._in(known_mask)
+        rng = self._rng(vk.size(0))
+        dp = _E.dp
+        if dp.active():
+            # this rank's rows of the global batch; one all-reduce of the packed statistics
+            B = vk.size(0)
+            buf = eng.packed_buffer(self) if hasattr(eng, "packed_buffer") else None
+            packed = eng.clamped_stats(self, vk, km, init, mu, CD, sample_h, sample_v, reclamp_negative, rng, out=buf)
+            dp.all_reduce_sum(packed)
+            return eng.apply_delta(self, packed, B * dp.world_size(), aux_lr_mult * lr, mom, sparsity=False)
+        return eng.clamped_step(self, vk, km, init, mu, aux_lr_mult * lr, mom, CD, sample_h, sample_v, reclamp_negative, rng)

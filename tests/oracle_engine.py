@@ -150,8 +150,9 @@ class OracleEngine:
         packed = gathered.view(torch.float32).sum(0)
         return self.apply_delta(rbm, packed, global_B, lr, mom)
 
-    def apply_delta(self, rbm, packed, global_B, lr, mom):
+    def apply_delta(self, rbm, packed, global_B, lr, mom, sparsity=None):
         st = self._state(rbm, True)
+        use_sparsity = st.sparsity if sparsity is None else sparsity
         V, H = st.W.shape
         p = _np(packed)
         o = V * H
@@ -162,7 +163,7 @@ class OracleEngine:
         st.W += st.W_m
         st.hb_m *= mom32
         st.hb_m += lr32 * p[o:o + H] / n
-        if st.sparsity:
+        if use_sparsity:
             st.hb_m += F32(-lr) * (p[o + H + V:o + 2 * H + V] / n - F32(st.sparsity_factor))
         st.hid_bias += st.hb_m
         st.vb_m *= mom32
@@ -209,8 +210,7 @@ class OracleEngine:
         s.done()
         return self._t(v)
 
-    def clamped_step(self, rbm, v_known, mask, init_steps, mu, lr, mom, cd_k, sample_h, sample_v, reclamp, rng):
-        st = self._state(rbm, True)
+    def _clamped_stats(self, st, v_known, mask, init_steps, mu, cd_k, sample_h, sample_v, reclamp, rng):
         s = _Src(rng)
         vk, km = _np(v_known), _np(mask)
         v_plus = self._run_chain(st, vk, km, init_steps, s, True, None if mu is None else _np(mu))
@@ -224,5 +224,23 @@ class OracleEngine:
         stats = dict(pos_assoc=(v_plus.T @ h_plus).astype(F32), neg_assoc=(v_neg.T @ h_neg).astype(F32),
                      pos_h_sum=h_plus.sum(0, dtype=F32), neg_h_sum=h_neg.sum(0, dtype=F32),
                      data_sum=v_plus.sum(0, dtype=F32), v_sum=v_neg.sum(0, dtype=F32))
-        O.apply_cd_update(st, stats, lr, mom, vk.shape[0], False)
+        return stats, v_plus, v_neg
+
+    def clamped_step(self, rbm, v_known, mask, init_steps, mu, lr, mom, cd_k, sample_h, sample_v, reclamp, rng):
+        st = self._state(rbm, True)
+        stats, v_plus, v_neg = self._clamped_stats(st, v_known, mask, init_steps, mu, cd_k, sample_h, sample_v, reclamp, rng)
+        O.apply_cd_update(st, stats, lr, mom, v_plus.shape[0], False)
         return self._t(np.array(((v_plus - v_neg) ** 2).mean(dtype=F32), F32)).reshape(())
+
+    def clamped_stats(self, rbm, v_known, mask, init_steps, mu, cd_k, sample_h, sample_v, reclamp, rng, out=None):
+        st = self._state(rbm)
+        x, v_plus, v_neg = self._clamped_stats(st, v_known, mask, init_steps, mu, cd_k, sample_h, sample_v, reclamp, rng)
+        V, H = st.W.shape
+        p = np.zeros(self.packed_floats(V, H), F32)
+        o = V * H
+        p[:o] = (x["pos_assoc"] - x["neg_assoc"]).ravel()
+        p[o:o + H] = x["pos_h_sum"] - x["neg_h_sum"]
+        p[o + H:o + H + V] = x["data_sum"] - x["v_sum"]
+        p[o + H + V:o + 2 * H + V] = x["pos_h_sum"]
+        p[o + 2 * H + V] = ((v_plus - v_neg) ** 2).sum(dtype=F32)
+        return self._t(p)

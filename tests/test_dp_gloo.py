@@ -97,3 +97,95 @@ def test_packed_layout_matches_header():
     for v, h in ((10000, 1500), (532, 256), (37, 19)):
         n = v * h + 2 * h + v + 1
         assert lib.imdbn_packed_delta_floats(v, h) == (n + 3) // 4 * 4
+
+
+# ---- the joint model under data parallelism: clamped updates, bias initialisation counters, epoch metrics ----
+J_SIZES, J_H, J_K, J_B, J_NB, J_EPOCHS = [60, 30], 20, 4, 16, 2, 9      # 9 epochs: crosses the 8-epoch warm-up
+
+
+def _make_joint(rank=None, world=1):
+    """Small iMDBN with fixed parameters; rank r's loader holds rows [r*per, (r+1)*per) of every global batch."""
+    from imdbn.models import iMDBN
+    from torch.utils.data import DataLoader, TensorDataset
+    g = np.random.Generator(np.random.PCG64(11))
+    n = J_B * J_NB
+    yi = np.arange(n) % J_K
+    proto = (g.random((J_K, J_SIZES[0])) > 0.6).astype(np.float32)
+    X = np.abs(proto[yi] - (g.random((n, J_SIZES[0])) > 0.9)).astype(np.float32)
+    Y = np.eye(J_K, dtype=np.float32)[yi]
+    W_img = (g.standard_normal((J_SIZES[0], J_SIZES[1])) / np.sqrt(J_SIZES[0])).astype(np.float32)
+    W_j = (g.standard_normal((J_SIZES[1] + J_K, J_H)) / np.sqrt(J_SIZES[1] + J_K)).astype(np.float32)
+    per = J_B // world
+    if rank is not None:
+        rows = np.concatenate([np.arange(b * J_B + rank * per, b * J_B + (rank + 1) * per) for b in range(J_NB)])
+        X, Y = X[rows], Y[rows]
+    dl = DataLoader(TensorDataset(torch.from_numpy(X), torch.from_numpy(Y)), batch_size=per if rank is not None else J_B, shuffle=False)
+    params = {"LEARNING_RATE": 0.1, "WEIGHT_PENALTY": 1e-4, "INIT_MOMENTUM": 0.5, "FINAL_MOMENTUM": 0.95,
+              "LEARNING_RATE_DYNAMIC": True, "CD": 1, "JOINT_CD": 1, "CROSS_GIBBS_STEPS": 4, "JOINT_AUX_COND_STEPS": 10}
+    mdl = iMDBN(J_SIZES, J_H, params=params, dataloader=dl, val_loader=dl, device=torch.device("cpu"), num_labels=J_K)
+    for r, W in ((mdl.image_idbn.layers[0], W_img), (mdl.joint_rbm, W_j)):
+        r.W.data = torch.from_numpy(W.copy())
+        r.W_m, r.hb_m, r.vb_m = torch.zeros_like(r.W.data), torch.zeros_like(r.hid_bias.data), torch.zeros_like(r.vis_bias.data)
+    return mdl
+
+
+def _joint_state(mdl):
+    jr = mdl.joint_rbm
+    h = mdl.joint_history
+    return dict(W=jr.W.data.numpy(), hb=jr.hid_bias.data.numpy(), vb=jr.vis_bias.data.numpy(), Wm=jr.W_m.numpy(),
+                zcm=mdl.z_class_mean.numpy(), n=np.array([r["n"] for r in h]), top1=np.array([r["text_top1"] for r in h]),
+                ce=np.array([r["text_ce"] for r in h]), mse=np.array([r["image_mse"] for r in h]),
+                cd=np.array([r["cd_loss"] if r["cd_loss"] is not None else -1.0 for r in h]))
+
+
+def _joint_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from imdbn import engine as E
+    from oracle_engine import OracleEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir(out_dir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E.set_engine_for_testing(OracleEngine())
+    E.dp.enable(mode="allreduce")
+    mdl = _make_joint(rank, world)
+    E.set_rng(E.PhiloxRng(SEED))
+    mdl.train_joint(J_EPOCHS)
+    np.savez(os.path.join(out_dir, f"joint_rank{rank}.npz"), **_joint_state(mdl))
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_joint_equals_single_rank(tmp_path, monkeypatch):
+    """train_epoch_clamped, init_joint_bias_from_data's counters and the metric sums of train_joint shard
+    by rows -- two ranks on half batches end at the single-process model (draws keyed on the global row)."""
+    import socket
+    import torch.multiprocessing as mp
+    from imdbn import engine as E
+    from oracle_engine import OracleEngine
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, PKG, HERE, os.environ.get("PYTHONPATH", "")])
+    mp.spawn(_joint_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    monkeypatch.chdir(tmp_path)
+    E.set_engine_for_testing(OracleEngine())
+    try:
+        mdl = _make_joint()
+        with E.use_rng(E.PhiloxRng(SEED)):
+            mdl.train_joint(J_EPOCHS)
+        ref = _joint_state(mdl)
+    finally:
+        E.set_engine_for_testing(None)
+    a, b = np.load(tmp_path / "joint_rank0.npz"), np.load(tmp_path / "joint_rank1.npz")
+    for k in ("W", "hb", "vb", "Wm", "zcm", "n", "top1", "ce", "mse", "cd"):
+        np.testing.assert_array_equal(a[k], b[k])                    # replicas and their reports stay identical
+    from golden_utils import rel_fro
+    np.testing.assert_array_equal(a["n"], ref["n"])
+    assert rel_fro(a["zcm"], ref["zcm"]) < 1e-6
+    for k, tol in (("W", 2e-5), ("hb", 1e-4), ("vb", 1e-4), ("Wm", 1e-4)):
+        assert rel_fro(a[k], ref[k]) < tol, k
+    assert np.allclose(a["top1"], ref["top1"]) and np.allclose(a["ce"], ref["ce"], rtol=1e-4) and np.allclose(a["mse"], ref["mse"], rtol=1e-4)
+    assert np.allclose(a["cd"], ref["cd"], rtol=1e-4)

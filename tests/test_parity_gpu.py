@@ -204,6 +204,33 @@ def test_stats_then_apply_equals_fused_update_for_multi_chunk_batches(B, _native
         assert_close(P.N(getattr(r1, k)), getattr(st, k), 1e-4, k, atol=2e-6)
 
 
+@pytest.mark.parametrize("sample_h,sample_v,reclamp", [(False, False, True), (True, True, False)])
+def test_clamped_stats_then_apply_equals_clamped_step_and_shards_add_up(sample_h, sample_v, reclamp, _native):
+    """Data-parallel clamped update: clamped_stats + apply_delta (no sparsity term) reproduces
+    clamped_step, and two row shards with Philox keyed on the global row sum to the unsharded statistics."""
+    from imdbn import engine as E
+    V, H, Dz, B = 276, 96, 260, 48
+    r1, st, g = _mk(V, H, [(Dz, V)], seed=4, sparsity=True, sparsity_factor=0.1)
+    r2, _, _ = _mk(V, H, [(Dz, V)], seed=4, sparsity=True, sparsity_factor=0.1)
+    y = np.eye(V - Dz, dtype=F32)[g.integers(0, V - Dz, B)]
+    vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+    vk[:, Dz:] = y; km[:, Dz:] = 1
+    kw = dict(CD=2, cond_init_steps=12, sample_h=sample_h, sample_v=sample_v, reclamp_negative=reclamp)
+    with E.use_rng(E.PhiloxRng(seed=17)):
+        l1 = r1.train_epoch_clamped(P.T(vk, DEV), P.T(km, DEV), 2, 10, **kw)
+    init = r2._nmf_steps(12, 3.0, 1.0, 0.9, 2, 0.9, 0.0)
+    args = (init, None, 2, sample_h, sample_v, reclamp)
+    packed = _native.clamped_stats(r2, P.T(vk, DEV), P.T(km, DEV), *args, E.PhiloxRng(seed=17)).clone()
+    s0 = _native.clamped_stats(r2, P.T(vk[:24], DEV), P.T(km[:24], DEV), *args, E.PhiloxRng(seed=17, row0=0)).clone()
+    s1 = _native.clamped_stats(r2, P.T(vk[24:], DEV), P.T(km[24:], DEV), *args, E.PhiloxRng(seed=17, row0=24)).clone()
+    assert_close(P.N(s0 + s1), P.N(packed), 2e-6, "shard sum of the clamped statistics", atol=2e-5)
+    lr, mom = r2._lr_mom(2)
+    l2 = _native.apply_delta(r2, packed, B, 0.3 * lr, mom, sparsity=False)
+    assert_close(float(l2), float(l1), 1e-5, "loss")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r2, k)), P.N(getattr(r1, k)), 1e-5, k, atol=2e-6)
+
+
 @pytest.mark.parametrize("V,H,R,Bl", [(640, 192, 2, 64), (2048, 512, 3, 64), (640, 192, 4, 40)])
 def test_factor_exchange_equals_single_process_and_allreduce_updates(V, H, R, Bl, _native):
     """Data-parallel factor exchange, emulated on one device: R ranks of Bl rows each run cd_factors (Philox keyed

@@ -13,5 +13,5 @@ timeout -k 10 120 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; e
 timeout -k 10 200 python bench.py --steps 200 --warmup 20 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -2 gpurun_out/bench.log
 # kernel trace of the same bench command (summary copied to profiles/ by hand)
 cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; echo "rocprof exit $?"
-cd $GRAFT_REPO_ROOT; find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -20
+cd $GRAFT_REPO_ROOT; find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -8 | cut -c1-180
 timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --force-dp > gpurun_out/bench_dp1.log 2>&1; echo "bench force-dp exit $?"; tail -1 gpurun_out/bench_dp1.log | cut -c1-260

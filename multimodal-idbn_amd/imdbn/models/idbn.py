@@ -51,7 +51,23 @@ class iDBN:
             self.val_batch, self.val_labels = next(iter(val_loader))
         except Exception:
             self.val_batch, self.val_labels = None, None
-        self.features = None                                                        # idbn.py:129 (side-car input)
+        # validation features for the evaluation side-car (idbn.py:129-144): a Subset over a base dataset that carries
+        # per-sample lists; any other loader leaves `features` at None, as in the reference
+        self.features = None
+        try:
+            indices = val_loader.dataset.indices
+            base = val_loader.dataset.dataset
+            feats = {
+                "Cumulative Area": torch.tensor([base.cumArea_list[i] for i in indices], dtype=torch.float32),
+                "Convex Hull": torch.tensor([base.CH_list[i] for i in indices], dtype=torch.float32),
+                "Labels": torch.tensor([base.labels[i] for i in indices], dtype=torch.float32),
+            }
+            density = getattr(base, "density_list", None)
+            if density is not None:
+                feats["Density"] = torch.tensor([density[i] for i in indices], dtype=torch.float32)
+            self.features = feats
+        except Exception:
+            pass
 
         for i in range(len(layer_sizes) - 1):                                       # idbn.py:149-161
             rbm = RBM(

@@ -92,7 +92,8 @@ class iMDBN(nn.Module):
         self.best_of_k = int(self.params.get("CROSS_BEST_OF_K", KBUF))
         self.aux_every_k = int(self.params.get("JOINT_AUX_EVERY_K", 0))
         self.aux_cond_steps = int(self.params.get("JOINT_AUX_COND_STEPS", 50))
-        self.features = None
+        # imdbn.py:170-187: same extraction as the image stack did from the same val_loader
+        self.features = getattr(self.image_idbn, "features", None)
         self.arch_str = f"IMG{'-'.join(map(str, layer_sizes_img))}_JOINT{joint_layer_size}"
 
     def _build_joint(self, Dz_img: int, joint_hidden: int):

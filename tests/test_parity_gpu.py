@@ -4,6 +4,8 @@ Tolerance (north_star): <= 1e-4 relative (Frobenius) on weights; the replayed dr
 reference consumed, so any larger deviation is a kernel bug or a Bernoulli flip at a sub-1e-6 margin
 (the assertion message says which).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -453,3 +455,79 @@ def test_dp_path_over_rccl_world1_equals_fused_update():
     for k in P.KEYS:
         assert_close(P.N(getattr(r2, k)), P.N(getattr(r1, k)), 1e-5, "dp " + k, atol=1e-7)
     assert abs(float(l1) - float(l2)) < 1e-6
+
+
+def test_probe_side_car_stays_on_the_device():
+    """Evaluation side-car: validation embeddings come from the engine and stay in HBM, the
+    linear probe runs there and agrees with its CPU run on the same inputs."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from imdbn.models import iDBN
+    from imdbn.utils import probe_utils as PU
+    g = np.random.default_rng(0)
+    K, n = 4, 256
+    yi = np.arange(n) % K
+    proto = (g.random((K, 200)) > 0.5).astype(F32)
+    X = np.abs(proto[yi] - (g.random((n, 200)) > 0.95)).astype(F32)
+    dl = DataLoader(TensorDataset(torch.from_numpy(X), torch.from_numpy(np.eye(K, dtype=F32)[yi])), batch_size=64)
+    params = {"LEARNING_RATE": 0.1, "WEIGHT_PENALTY": 1e-4, "INIT_MOMENTUM": 0.5, "FINAL_MOMENTUM": 0.95,
+              "LEARNING_RATE_DYNAMIC": True, "CD": 1}
+    import os, tempfile
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            net = iDBN([200, 64, 32], params, dl, dl, torch.device(DEV))
+            net.features = {"Cumulative Area": X.sum(1), "Convex Hull": X[:, :100].sum(1), "Labels": yi}
+            emb, feats = PU.compute_val_embeddings_and_features(net)
+            assert emb.is_cuda and emb.shape == (n, 32) and all(t.is_cuda for t in feats.values())
+            st = O.RBMState.create(P.N(net.layers[0].W.data), 0.1, 1e-4, 0.5, hid_bias=P.N(net.layers[0].hid_bias.data))
+            st2 = O.RBMState.create(P.N(net.layers[1].W.data), 0.1, 1e-4, 0.5, hid_bias=P.N(net.layers[1].hid_bias.data))
+            assert_close(P.N(emb), O.forward(st2, O.forward(st, X)), 1e-5, "embeddings vs oracle")
+            y, edges = PU.make_bin_labels(feats["labels"], n_bins=4)
+            tr, te = PU.stratified_split(y, 0.25, 1)
+            tr_t, te_t = torch.as_tensor(tr, device=DEV), torch.as_tensor(te, device=DEV)
+            torch.manual_seed(5)
+            acc, yt, yp = PU.train_linear_classifier(emb[tr_t], y[tr_t], emb[te_t], y[te_t], torch.device(DEV), 4,
+                                                     max_steps=120, return_tensors=True)
+            assert yp.is_cuda
+            torch.manual_seed(5)
+            acc_c, _, yp_c = PU.train_linear_classifier(emb[tr_t].cpu(), y[tr_t].cpu(), emb[te_t].cpu(), y[te_t].cpu(),
+                                                        torch.device("cpu"), 4, max_steps=120)
+            assert abs(float(acc) - acc_c) <= 0.02 and np.mean(np.array(yp.cpu().tolist()) == np.array(yp_c)) >= 0.97
+            res = PU.log_linear_probe(net, epoch=0, n_bins=4, steps=60, save_csv=False)
+            assert set(res) == {"cum_area", "convex_hull", "labels"}
+        finally:
+            os.chdir(cwd)
+
+
+def test_device_loader_feeds_training_from_hbm(tmp_path):
+    """imdbn.datasets: the split lives in HBM as uint8, batches are device tensors, the stack trains
+    from them and the validation features line up with the side-car's embeddings."""
+    from imdbn import engine as E
+    from imdbn.datasets import create_dataloaders_uniform
+    from imdbn.models import iDBN
+    from imdbn.utils import probe_utils as PU
+    g = np.random.default_rng(2)
+    n, K = 640, 8
+    img = (g.random((n, 100, 100)) > 0.9).astype(np.uint8)
+    np.savez(tmp_path / "stimuli.npz", D=img, N_list=(np.arange(n) % K) + 1, cumArea_list=img.reshape(n, -1).sum(1),
+             CH_list=g.random(n).astype(F32))
+    tr, va, te = create_dataloaders_uniform(path2data=str(tmp_path), data_name="stimuli.npz", batch_size=64, multimodal_flag=False)
+    x, y = next(iter(tr))
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape == (64, 10000) and y.is_cuda
+    assert tr._x.dtype == torch.uint8 and tr._x.is_cuda and set(x.unique().tolist()) <= {0.0, 1.0}
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        params = {"LEARNING_RATE": 0.1, "WEIGHT_PENALTY": 1e-4, "INIT_MOMENTUM": 0.5, "FINAL_MOMENTUM": 0.95,
+                  "LEARNING_RATE_DYNAMIC": True, "CD": 1}
+        net = iDBN([10000, 256, 64], params, tr, va, torch.device(DEV))
+        assert set(net.features) == {"Cumulative Area", "Convex Hull", "Labels"}
+        w0 = net.layers[0].W.data.clone()
+        with E.use_rng(E.PhiloxRng(1)):
+            net.train(1)
+        assert torch.isfinite(net.layers[0].W.data).all() and not torch.equal(w0, net.layers[0].W.data)
+        emb, feats = PU.compute_val_embeddings_and_features(net)
+        assert emb.is_cuda and emb.shape == (len(va.dataset), 64) and feats["labels"].numel() == emb.size(0)
+    finally:
+        os.chdir(cwd)

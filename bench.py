@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--ksplit-up", type=int, default=0)
     ap.add_argument("--ksplit-down", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not hand train_epoch the following batch (next_data=)")
     ap.add_argument("--force-dp", action="store_true", help="take the stats/all-reduce/apply path even with one rank")
     ap.add_argument("--no-k3-events", action="store_true", help="do not bracket K3 with HIP events in the timed region")
     ap.add_argument("--dp-mode", default="factors", choices=["factors", "allreduce"],
@@ -155,7 +156,10 @@ def main():
     E.set_rng(E.PhiloxRng(seed=2, row0=rank * B))
 
     def step(i):
-        return rbm.train_epoch(batches[i % len(batches)], 0, 1, CD=1)
+        # a training loop knows its next batch (iDBN.train does the same lookahead): its operand forms are prepared
+        # during this update's weight kernel.  Same work, same results, no separate preparation launch.
+        nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
+        return rbm.train_epoch(batches[i % len(batches)], 0, 1, CD=1, next_data=nxt)
 
     def sync():
         if world > 1:

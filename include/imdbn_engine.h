@@ -109,6 +109,15 @@ typedef struct imdbn_cd_opts {
     int32_t sample_h;       /* clamped step only (rbm.py:462) */
     int32_t sample_v;       /* clamped step only (rbm.py:468) */
     int32_t reclamp_negative; /* clamped step only (rbm.py:464) */
+    /* -- next-batch prefetch (imdbn_rbm_cd_step only; all zero = off).  The operand forms of a batch are a pure
+     * function of the batch: cd_step can prepare those of the FOLLOWING batch with extra blocks of its first
+     * negative-phase launch, into prefetch slot 1 or 2 of the workspace, and a later cd_step on the same workspace is told that
+     * its `data` already sits in that slot.  The caller guarantees the batch was not modified in between. */
+    const float* next_data; /* [B][V] fp32 batch to prepare during this call (NULL: none); honoured only when
+                               imdbn_rbm_prefetch_ok() says so for this descriptor and batch size */
+    int64_t ld_next;
+    int32_t next_slot;      /* 1 or 2: where to put it (must differ from data_slot) */
+    int32_t data_slot;      /* 0: prepare `data` now (default); 1 / 2: `data` was prefetched into that slot */
 } imdbn_cd_opts;
 
 /* ---- plumbing ------------------------------------------------------------------------- */
@@ -161,6 +170,9 @@ int imdbn_rbm_gibbs_step(const imdbn_rbm_desc* d, const float* v, int64_t ldv, i
 int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B,
                       const imdbn_cd_opts* o, imdbn_rng* rng, float* loss_out,
                       void* ws, size_t ws_bytes, imdbn_stream_t stream);
+/* 1 when cd_step on this descriptor / batch size honours imdbn_cd_opts.next_data (16-B aligned weight rows: the
+ * float4 fused K2 carries the prefetch blocks), else 0 -- then next_data is ignored and nothing may be assumed prefetched. */
+int imdbn_rbm_prefetch_ok(const imdbn_rbm_desc* d, int B);
 
 /* ---- data-parallel split of the same update ------------------------------ */
 /* packed layout (floats): [dW V*H][dc H][db V][sum P+ H][sq-err sum 1][pad to 4] */

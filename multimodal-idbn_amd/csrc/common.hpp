@@ -12,7 +12,7 @@ typedef uint16_t bf16_t;     // raw bf16 bits in memory
 constexpr int WAVE = 64;
 
 // ------------------------------------------------------------------------------------------
-// Philox-4x32-10.  counter = (column, global row, draw_lo, draw_hi), key = seed.
+// Philox-4x32-10.  counter = (column, global row [normal] or global row >> 2 [uniform], draw_lo, draw_hi), key = seed.
 // numpy twin: oracle/draws.py:PhiloxStream.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
@@ -42,9 +42,47 @@ __device__ __forceinline__ uint4 draw_block(const DrawSrc& s, int b, int n) {
                          make_uint2((uint32_t)s.seed, (uint32_t)(s.seed >> 32)));
 }
 
+// Uniform draws: the four rows of a global 4-row group share ONE Philox block (counter row = global row >> 2,
+// component = global row & 3).  A Philox-4x32-10 call is ~40 quarter-rate integer multiplies (~900 cycles per wave):
+// with one call per element it was 3.4 of the 3.9 us of the fused K2 epilogue (8 rows per thread -> 8 calls, now 2).
+__device__ __forceinline__ uint4 draw_block4(const DrawSrc& s, uint64_t grow, int n) {
+    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)(grow >> 2), (uint32_t)s.draw, (uint32_t)(s.draw >> 32)),
+                         make_uint2((uint32_t)s.seed, (uint32_t)(s.seed >> 32)));
+}
+__device__ __forceinline__ float u24(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }   // 2^-24
+__device__ __forceinline__ uint32_t pick4(const uint4& x, int c) { return c == 0 ? x.x : (c == 1 ? x.y : (c == 2 ? x.z : x.w)); }
+
 __device__ __forceinline__ float draw_uniform(const DrawSrc& s, int b, int n) {
     if (s.tape) return s.tape[(int64_t)b * s.N + n];
-    return (float)(draw_block(s, b, n).x >> 8) * 5.9604644775390625e-08f;   // 2^-24
+    const uint64_t g = (uint64_t)(s.row0 + b);
+    return u24(pick4(draw_block4(s, g, n), (int)(g & 3)));
+}
+
+// R consecutive rows b0 .. b0+R-1 (clamped to bmax) of column n; R = 8 -> two Philox blocks, R = 2 -> one, when the
+// rows line up with the 4-row groups (the usual case: b0 and row0 multiples of R), else element by element.
+template <int R>
+__device__ __forceinline__ void draw_uniform_rows(const DrawSrc& s, int b0, int bmax, int n, float (&u)[R]) {
+    static_assert(R == 8 || R == 2, "row tiles of the epilogues");
+    if (s.tape) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) u[i] = s.tape[(int64_t)min(b0 + i, bmax) * s.N + n];
+        return;
+    }
+    const uint64_t g0 = (uint64_t)(s.row0 + b0);
+    if ((g0 & (R == 8 ? 3 : 1)) == 0 && b0 + R - 1 <= bmax) {
+        if constexpr (R == 8) {
+            const uint4 x = draw_block4(s, g0, n), y = draw_block4(s, g0 + 4, n);
+            u[0] = u24(x.x); u[1] = u24(x.y); u[2] = u24(x.z); u[3] = u24(x.w);
+            u[4] = u24(y.x); u[5] = u24(y.y); u[6] = u24(y.z); u[7] = u24(y.w);
+        } else {
+            const uint4 x = draw_block4(s, g0, n);
+            const bool up = (g0 & 2) != 0;
+            u[0] = u24(up ? x.z : x.x); u[1] = u24(up ? x.w : x.y);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) u[i] = draw_uniform(s, min(b0 + i, bmax), n);
 }
 
 __device__ __forceinline__ float draw_normal(const DrawSrc& s, int b, int n) {

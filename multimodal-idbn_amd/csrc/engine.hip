@@ -29,6 +29,7 @@ bool g_no_fused_up = false;
 int g_k4_rows = 0;          // tuning: batch rows per chain-kernel block (0 = automatic)
 int g_no_rank_loop = 0;     // testing: one update-kernel launch per gathered rank block
 int g_no_chain_kernel = 0;  // testing: run chains as one launch per half step
+int g_no_prefetch = 0;   // testing: ignore imdbn_cd_opts.next_data
 int g_no_bits = 0;  // testing: never use the bit-packed hidden operand
 int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
@@ -96,6 +97,8 @@ struct Layout {
     float* cs_hpos; float* cs_hneg; float* cs_vpos; float* cs_vneg;
     float* loss_part; int n_loss_slots;
     size_t fb_off, fb_bytes;      // the factor block inside the workspace
+    // prefetch slots 1 / 2: operand forms of a batch prepared ahead of its CD step (imdbn_cd_opts.next_data)
+    bf16_t* pf_rm[2]; bf16_t* pf_tr[2]; int* pf_flags[2]; float* pf_cs[2];
     ChainRec* chain_recs;   // per-step schedule of the row-parallel chain kernel
     bf16_t* k4_planes; int64_t k4_plane_stride;      // fragment-ordered bf16 weight planes [2 directions][3 terms]
     int down_tr;            // visible rows per block of the fused K2 (<= 32): balances the row tiles over the CUs
@@ -176,6 +179,12 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.f_vp = (float*)take((size_t)L.Bp * V * 4);
     for (int i = 0; i < 2; ++i) L.f_v[i] = (float*)take((size_t)L.Bp * V * 4);
     L.chain_recs = (ChainRec*)take(sizeof(ChainRec) * CHAIN_MAX_STEPS);
+    for (int i = 0; i < 2; ++i) {
+        L.pf_rm[i] = (bf16_t*)take((size_t)3 * L.Bp * L.Vpad * 2);
+        L.pf_tr[i] = (bf16_t*)take((size_t)3 * V * L.Bp * 2);
+        L.pf_flags[i] = (int*)take((size_t)L.P * cdiv(L.Vpad, 64) * 4);
+        L.pf_cs[i] = (float*)take((size_t)L.P * V * 4);
+    }
     L.k4_plane_stride = 0; L.k4_planes = nullptr;
     if (V <= 1024 && H <= 1024) {
         L.k4_plane_stride = (int64_t)std::max(cdiv(H, 16) * cdiv(V, 32), cdiv(V, 16) * cdiv(H, 32)) * 512;
@@ -238,6 +247,7 @@ struct Ctx {
     int nw;         // weight terms
     int rt;         // terms of a real-valued activation operand
     bool hid_bits_ok = false;      // L.hid_bits describes the current contents of L.hid_rm
+    bool data_prepped = false;     // cd_phases: the data-side operands are already in place (prefetch slot)
     Ctx(const imdbn_rbm_desc* d_, imdbn_rng* r, hipStream_t s_) : d(d_), s(s_), rng(r) {
         nw = d->mode == IMDBN_FAST_BF16 ? 1 : 3;
         rt = nw;
@@ -263,6 +273,15 @@ int check_desc(const imdbn_rbm_desc* d, bool need_momentum) {
     }
     if (d->mode != IMDBN_PARITY_F32 && d->mode != IMDBN_FAST_BF16) return fail(IMDBN_E_INVALID, "bad mode %d", d->mode);
     return 0;
+}
+
+// the CD step reads its data-side operands from prefetch slot `slot` (1 / 2) instead of the default buffers
+void use_slot(Layout& L, int slot) {
+    if (slot < 1 || slot > 2) return;
+    std::swap(L.vis_rm[0], L.pf_rm[slot - 1]);
+    std::swap(L.vis_tr[0], L.pf_tr[slot - 1]);
+    std::swap(L.flags, L.pf_flags[slot - 1]);
+    std::swap(L.cs_vpos, L.pf_cs[slot - 1]);
 }
 
 int setup(Ctx& c, int B, void* ws, size_t ws_bytes) {
@@ -302,7 +321,7 @@ FinishArgs new_finish() {
 }
 
 // one propagation: partial GEMM + finish (+ group kernel)
-int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
+int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr) {
     const Layout& L = c.L;
     const imdbn_rbm_desc* d = c.d;
     base_finish_args(c, up, f);
@@ -356,8 +375,19 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f) {
 #define LAUNCH_DOWN_A(NW, V4) \
     do { if (abits) LAUNCH_DOWN(NW, V4, 1, true); else if (in.terms == 1) LAUNCH_DOWN(NW, V4, 1, false); \
          else if (in.terms == 3) LAUNCH_DOWN(NW, V4, 3, false); else LAUNCH_DOWN(NW, V4, 0, false); } while (0)
-        if (c.nw == 3) { if (vec4) LAUNCH_DOWN_A(3, true); else LAUNCH_DOWN_A(3, false); }
-        else           { if (vec4) LAUNCH_DOWN_A(1, true); else LAUNCH_DOWN_A(1, false); }
+        if (next) {
+            // + one block per (64-column tile, batch chunk) of the NEXT batch behind the weight tiles (prep_item_body)
+            if (!vec4 || in.terms != 1) return fail(IMDBN_E_INVALID, "internal: next-batch prep on an ineligible K2");
+            const int main_nbx = (int)grid.x;
+            dim3 gn(grid.x + cdiv(std::max(next->N, next->op.ldrm), 64), 1, mb);
+#define LAUNCH_DOWN_N(NW, BITS) \
+    hipLaunchKernelGGL((gemm_down_fused_next<NW, BITS>), gn, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, f, L.down_tr, abits, L.ldbits, *next, main_nbx)
+            if (c.nw == 3) { if (abits) LAUNCH_DOWN_N(3, true); else LAUNCH_DOWN_N(3, false); }
+            else           { if (abits) LAUNCH_DOWN_N(1, true); else LAUNCH_DOWN_N(1, false); }
+#undef LAUNCH_DOWN_N
+        }
+        else if (c.nw == 3) { if (vec4) LAUNCH_DOWN_A(3, true); else LAUNCH_DOWN_A(3, false); }
+        else                { if (vec4) LAUNCH_DOWN_A(1, true); else LAUNCH_DOWN_A(1, false); }
 #undef LAUNCH_DOWN_A
 #undef LAUNCH_DOWN
         HIPCHK(hipGetLastError());
@@ -406,6 +436,12 @@ int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_
 }
 
 int launch_bias(Ctx& c, const BiasArgs& b);
+
+// Next-batch preparation rides on the fused K2 of the first negative-phase step (gemm_down_fused_next: float4 weight
+// rows, single-term hidden activations -- what imdbn_rbm_cd_step always launches when the weight rows are aligned).
+bool prefetch_available(const imdbn_rbm_desc* d) {
+    return !g_no_prefetch && d->H % 4 == 0 && d->H >= 4 && d->ldw % 4 == 0 && (((uintptr_t)d->W) & 15) == 0;
+}
 
 int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms, const int* vpos_flag, int vneg_terms,
                  float n, float* delta, const BiasArgs* bias = nullptr) {
@@ -478,11 +514,11 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
 }
 
 // rbm.py:199-209: positive phase, CD-k Gibbs, statistics left in the workspace operand buffers.
-int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o) {
+int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, const PrepArgs* next = nullptr) {
     const Layout& L = c.L;
     const int B = L.B;
     if (o->cd_k < 1) return fail(IMDBN_E_INVALID, "CD=%d (the reference needs CD>=1, rbm.py:204-209)", o->cd_k);
-    CHK(prep(c, data, ldd, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], L.flags, L.cs_vpos));
+    if (!c.data_prepped) CHK(prep(c, data, ldd, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], L.flags, L.cs_vpos));
     // positive phase: P+ = up(data); h = 1[P+ > U]
     {
         FinishArgs f = new_finish();
@@ -504,7 +540,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o) {
             f.op.tr = L.vis_tr[1]; f.op.tr_terms = 1; f.tr_src = 2;
             f.colsum_part = L.cs_vneg; f.colsum_src = 2;
             f.loss_ref = data; f.ld_ref = ldd; f.loss_src = 1; f.loss_part = L.loss_part;
-            CHK(prop(c, false, OpIn{L.hid_rm, 1, nullptr}, f));
+            CHK(prop(c, false, OpIn{L.hid_rm, 1, nullptr}, f, it == 0 ? next : nullptr));
         }
         {   // h_prob = up(v); h = 1[h_prob > U]  (the last draw is consumed but unused, rbm.py:208)
             FinishArgs f = new_finish();
@@ -707,6 +743,7 @@ int imdbn_set_option(const char* name, int value) {
     else if (!strcmp(name, "no_chain_kernel")) g_no_chain_kernel = value;
     else if (!strcmp(name, "chain_rows")) { if (value < 0 || value > 16) return fail(IMDBN_E_INVALID, "chain_rows must be in [0, 16]"); g_k4_rows = value; }
     else if (!strcmp(name, "no_bits")) g_no_bits = value;
+    else if (!strcmp(name, "no_prefetch")) g_no_prefetch = value;
     else if (!strcmp(name, "dbg")) g_dbg = value;
     else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
     else if (!strcmp(name, "no_fused_up")) g_no_fused_up = value != 0;
@@ -848,13 +885,32 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
                       imdbn_rng* rng, float* loss_out, void* ws, size_t ws_bytes, imdbn_stream_t stream) {
     CHK(check_desc(d, true));
     if (!data || !o || ldd < d->V) return fail(IMDBN_E_INVALID, "cd_step: bad argument");
+    if (o->data_slot < 0 || o->data_slot > 2 || (o->next_data && (o->next_slot < 1 || o->next_slot > 2 || o->next_slot == o->data_slot || o->ld_next < d->V)))
+        return fail(IMDBN_E_INVALID, "cd_step: bad prefetch slots (data %d, next %d)", o->data_slot, o->next_slot);
     Ctx c(d, rng, S(stream));
     CHK(setup(c, B, ws, ws_bytes));
-    CHK(cd_phases(c, data, ldd, o));
+    const int next_rows = (o->next_data && prefetch_available(d)) ? 1 : 0;
+    PrepArgs pn;
+    memset(&pn, 0, sizeof(pn));
+    if (next_rows > 0) {            // target buffers are taken before the data slot is swapped in
+        const Layout& L = c.L;
+        const int t = o->next_slot - 1;
+        pn.in = o->next_data; pn.ld = o->ld_next; pn.B = L.B; pn.Bp = L.Bp; pn.N = L.V;
+        pn.op.rm = L.pf_rm[t]; pn.op.ldrm = L.Vpad; pn.op.rm_ts = (int64_t)L.Bp * L.Vpad; pn.op.rm_terms = 3; pn.op.Bp = L.Bp;
+        pn.op.tr = L.pf_tr[t]; pn.op.tr_ts = (int64_t)L.V * L.Bp; pn.op.tr_terms = 3;
+        pn.flag = L.pf_flags[t]; pn.colsum_part = L.pf_cs[t];
+    }
+    if (o->data_slot) { use_slot(c.L, o->data_slot); c.data_prepped = true; }
+    CHK(cd_phases(c, data, ldd, o, next_rows > 0 ? &pn : nullptr));
     CHK(c.rng.finish());
     const BiasArgs bias = make_bias(c, o, o->sparsity != 0, (float)B, loss_out);
     CHK(launch_assoc(c, 0, o, c.nw == 1 ? 1 : 0, c.L.flags, 1, (float)B, nullptr, &bias));
     return 0;
+}
+
+int imdbn_rbm_prefetch_ok(const imdbn_rbm_desc* d, int B) {
+    if (check_desc(d, true) != 0 || B <= 0) return 0;
+    return prefetch_available(d) ? 1 : 0;
 }
 
 // bias / sparsity / error tail of the packed statistics buffer (after the V*H delta-W floats)

@@ -198,9 +198,10 @@ __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, 
     const int vmode = a.vmode, colsum_src = a.colsum_src, loss_src = a.loss_src;
     const bool has_ref = a.loss_ref != nullptr;
     float* const out_prob = a.out_prob; float* const out_final = a.out_final;
-    float xp[R], xf[R];
+    float xp[R], xf[R], us[R];
     float lsum = 0.f;
     csum = 0.f;
+    if (vmode != 0) draw_uniform_rows<R>(a.uni, b0, a.B - 1, cc, us);      // draws for padded rows / columns: clamped, discarded
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int b = b0 + i;
@@ -218,7 +219,7 @@ __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, 
         if (vmode == 0) {
             v = mixed;
         } else {
-            const float u = draw_uniform(a.uni, bd, cc);
+            const float u = us[i];
             if (vmode == 1) {
                 const float smp = (p > u) ? 1.f : 0.f;
                 v = clamp ? (smp * (1.0f - sd.mk[i]) + sd.kn[i] * sd.mk[i]) : smp;
@@ -523,6 +524,50 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
         if (a.flag && c == 0) a.flag[blockIdx.y * gridDim.x + blockIdx.x] = (fl[0] | fl[1] | fl[2] | fl[3]);
         if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)blockIdx.y * a.N + col] = ((cs[0][c] + cs[1][c]) + cs[2][c]) + cs[3][c];
     }
+}
+
+// prep_operand of the NEXT batch as extra blocks of another launch of the step (the operand forms are a pure function
+// of the batch): one block = one item (64-column tile tx, 64-row chunk mb); thread = (column, 16 consecutive rows = two
+// 8-row groups), so column sums and exactness flags need no cross-thread step, the [col][row] planes leave as 16-B
+// stores and the K16-blocked form goes through a 24 KB LDS stage (`rmst`, the host kernel's reduction buffer).
+// The barrier is LDS-only (s_waitcnt lgkmcnt + s_barrier): a __syncthreads() also drains the global stores.
+// Plain prep only (no chain mix).  Same outputs, bit for bit, as the prep_operand kernel (same pieces, same summation
+// order of the column sums).
+//
+// Where it rides was measured (tools/prefetch_probe.py): on the 16 CUs the weight-update kernel K3 leaves idle it is
+// hopeless -- under K3's ~5 TB/s read+write stream a store is acknowledged after ~10 us and a wave holds at most 64
+// unacknowledged memory operations (vmcnt, shared by loads and stores on gfx950): 4-6 us per item, 90 us for 13 items
+// per block, with one item of lookahead, three, or loader waves (LDS-DMA) separated from the storing waves.  As a
+// third resident block per CU of the fused K2 (read-only stream, 23 us) the same work is done a few us into the launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void prep_item_body(const PrepArgs& a, int tx, int mb, bf16_t* rmst) {
+    const int c = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int ntx = (max(a.N, a.op.ldrm) + 63) / 64;
+    const int col = tx * 64 + c, cc = min(col, a.N - 1);
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = a.in[(int64_t)min(mb * 64 + 16 * kq + i, a.B - 1) * a.ld + cc];
+    const RmStage stg{rmst, 4, 64, tx * 64, mb * 64};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int b0 = mb * 64 + 16 * kq + 8 * hf, by = b0 >> 3;
+        float x[8];
+        bool inexact = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i] = (col < a.N && b0 + i < a.B) ? v[8 * hf + i] : 0.f;
+            inexact |= (__float_as_uint(x[i]) & 0xFFFFu) != 0u;
+        }
+        // the order of prep_operand: four row pairs, combined left to right
+        const float csum = (((0.f + x[0] + x[1]) + (0.f + x[2] + x[3])) + (0.f + x[4] + x[5])) + (0.f + x[6] + x[7]);
+        const bool any = __any(inexact ? 1 : 0) != 0;               // the wave = this group's 64 columns
+        store_forms<8>(a.op, x, true, true, b0, col, a.N, a.Bp, &stg);
+        if (a.flag && c == 0) a.flag[by * ntx + tx] = any ? 1 : 0;
+        if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)by * a.N + col] = csum;
+    }
+    lds_barrier();
+    flush_rm_stage(a.op, stg);
 }
 
 // Free energy of visible configurations (imdbn/utils/energy_utils.py:19-28):

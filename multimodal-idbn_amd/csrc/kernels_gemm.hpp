@@ -498,6 +498,25 @@ __global__ __launch_bounds__(256, 2) void gemm_down_fused(
 
 // K1 fused with its epilogue for SHORT visible dimensions (K = V <= 1024: joint RBM, chains): same
 // structure as gemm_down_fused with the [K][N] weight access; no split-K slabs, one launch per half step.
+// The fused K2 of the first negative-phase step carrying the preparation of the NEXT batch (prep_item_body): the
+// launch gets `prep_nbx` extra blocks per batch chunk behind its `main_nbx` weight tiles.  They become a third resident
+// block on a CU (K2 runs two), load 16 values per thread, and are gone a few us into the 23 us launch.
+// Own instantiations (single-term activations only: the CD step), so the plain kernels stay as tuned.
+template <int NW, bool BITS>
+__global__ __launch_bounds__(256, 2) void gemm_down_fused_next(
+    const float* __restrict__ W, int64_t ldw, int K, int N,
+    const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
+    const FinishArgs fa, int tile_rows, const uint32_t* __restrict__ abits, int ldbits, const PrepArgs next, int main_nbx) {
+    __shared__ float red[4 * 32 * 64];
+    __shared__ float tile[64][33];
+    if ((int)blockIdx.x >= main_nbx) {
+        prep_item_body(next, blockIdx.x - main_nbx, blockIdx.z, reinterpret_cast<bf16_t*>(red));
+        return;
+    }
+    stamp((fa.dbg & 128) != 0, blockIdx.z * main_nbx + blockIdx.x, 0);
+    down_fused_body<false, NW, true, 1, BITS>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, abits, ldbits, blockIdx.x, blockIdx.z, main_nbx);
+}
+
 template <int NW>
 __global__ __launch_bounds__(256, 2) void gemm_up_fused(
     const float* __restrict__ W, int64_t ldw, int K, int N,

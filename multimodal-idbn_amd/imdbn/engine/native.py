@@ -45,7 +45,8 @@ class ChainStep(C.Structure):
 class CdOpts(C.Structure):
     _fields_ = [("cd_k", C.c_int32), ("lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float),
                 ("sparsity", C.c_int32), ("sparsity_target", C.c_float),
-                ("sample_h", C.c_int32), ("sample_v", C.c_int32), ("reclamp_negative", C.c_int32)]
+                ("sample_h", C.c_int32), ("sample_v", C.c_int32), ("reclamp_negative", C.c_int32),
+                ("next_data", C.c_void_p), ("ld_next", C.c_int64), ("next_slot", C.c_int32), ("data_slot", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -72,6 +73,7 @@ SIGNATURES = {
     "imdbn_rbm_gibbs_step": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _INT, _INT, C.POINTER(Rng), _P, _P, _P, _P, _P, _SZ, _P]),
     "imdbn_rbm_cd_step": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
     "imdbn_packed_delta_floats": (_SZ, [_INT, _INT]),
+    "imdbn_rbm_prefetch_ok": (_INT, [C.POINTER(RbmDesc), _INT]),
     "imdbn_rbm_cd_stats": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
     "imdbn_rbm_apply_delta": (_INT, [C.POINTER(RbmDesc), _P, _INT, C.POINTER(CdOpts), _P, _P]),
     "imdbn_factor_block": (_INT, [_INT, _INT, _INT, C.POINTER(_SZ), C.POINTER(_SZ)]),

@@ -103,12 +103,19 @@ class iDBN:
         self.loss_history = []
         for epoch in range(int(epochs)):
             losses = []
-            for img, _ in batches(self.dataloader):
-                v = img.to(self.device).view(img.size(0), -1).float()
-                for rbm in self.layers:
-                    loss = rbm.train_epoch(v, epoch, epochs, CD=self.cd_k)
+            # one batch of lookahead: the first layer prepares the operand forms of the following batch during its
+            # weight update (RBM.train_epoch next_data=); the batches and their order are unchanged
+            dev_batch = lambda item: None if item is None else item[0].to(self.device).view(item[0].size(0), -1).float()
+            it = iter(batches(self.dataloader))
+            cur = dev_batch(next(it, None))
+            while cur is not None:
+                nxt = dev_batch(next(it, None))
+                v = cur
+                for li, rbm in enumerate(self.layers):
+                    loss = rbm.train_epoch(v, epoch, epochs, CD=self.cd_k, next_data=nxt if li == 0 else None)
                     v = rbm.forward(v)
                     losses.append(loss)
+                cur = nxt
             if losses:
                 ep = torch.stack([l.reshape(()) for l in losses]).float().cpu()
                 self.loss_history.append(ep)

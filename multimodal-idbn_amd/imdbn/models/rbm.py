@@ -154,8 +154,14 @@ class RBM(nn.Module):
 
     # ---- CD-k update (rbm.py:180-227) -----------------------------------------------------------
     @torch.no_grad()
-    def train_epoch(self, data: torch.Tensor, epoch: int, max_epochs: int, CD: int = 1):
+    def train_epoch(self, data: torch.Tensor, epoch: int, max_epochs: int, CD: int = 1,
+                    next_data: Optional[torch.Tensor] = None):
         """One CD-k update on one mini-batch (the name is the reference's); returns the 0-d MSE loss.
+
+        ``next_data`` (extension, optional): the batch the following ``train_epoch`` call will receive.  Its operand
+        forms are prepared by extra blocks of one of this call's launches; hand that same tensor, unmodified, to the next
+        call and it skips its own preparation (results are bit-identical either way; a modified, different or
+        ineligible tensor is simply prepared again).
 
         With data parallelism enabled (``imdbn.engine.dp.enable()``) ``data`` is this rank's shard
         of the global batch: the ranks exchange their factor blocks (or all-reduce the statistics, see
@@ -177,6 +183,8 @@ class RBM(nn.Module):
             packed = eng.cd_stats(self, x, CD, rng, out=buf)
             dp.all_reduce_sum(packed)
             return eng.apply_delta(self, packed, B * dp.world_size(), lr, mom)
+        if next_data is not None:
+            return eng.cd_step(self, x, lr, mom, CD, rng, next_data=next_data)
         return eng.cd_step(self, x, lr, mom, CD, rng)
 
     # ---- schedules (rbm.py:229-238) -------------------------------------------------------------

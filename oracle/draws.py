@@ -115,12 +115,13 @@ class PhiloxStream:
     one per draw) has element ``(b, n)`` generated from
 
         key     = (seed_lo, seed_hi)
-        counter = (n, row0 + b, s_lo, s_hi)   -> 4 x uint32 ``x[0..3]``
-        uniform = (x[0] >> 8) * 2^-24
-        normal  = sqrt(-2 ln u1) * cos(2 pi u2),  u1 = ((x[0]>>8)+1) * 2^-24, u2 = (x[1]>>8) * 2^-24
+        normal : counter = (n, row0 + b, s_lo, s_hi) -> ``x[0..3]``;
+                 sqrt(-2 ln u1) * cos(2 pi u2),  u1 = ((x[0]>>8)+1) * 2^-24, u2 = (x[1]>>8) * 2^-24
+        uniform: counter = (n, (row0 + b) >> 2, s_lo, s_hi) -> ``x[0..3]``;  (x[(row0 + b) & 3] >> 8) * 2^-24
+                 (the four rows of a global 4-row group share one Philox block: csrc/common.hpp draw_uniform_rows)
 
-    i.e. one Philox block per element keyed on the *global* row index, so the value
-    does not depend on tiling or on how the batch is sharded over ranks.
+    i.e. keyed on the *global* row index, so the value does not depend on tiling or on how
+    the batch is sharded over ranks.
     Categorical draws use inverse-CDF on the uniform of element ``(b, group_index)``.
     """
 
@@ -139,10 +140,21 @@ class PhiloxStream:
         return philox4x32_10(cols, rows, np.uint32(s & 0xFFFFFFFF), np.uint32((s >> 32) & 0xFFFFFFFF),
                              self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
 
+    def _uniform_block(self, shape):
+        B, N = int(shape[0]), int(shape[1])
+        s = self.offset
+        self.offset += 1
+        g = np.arange(B, dtype=np.uint64) + np.uint64(self.row0)
+        cols = np.arange(N, dtype=np.uint32)[None, :]
+        x = philox4x32_10(cols, (g >> np.uint64(2)).astype(np.uint32)[:, None], np.uint32(s & 0xFFFFFFFF),
+                          np.uint32((s >> 32) & 0xFFFFFFFF), self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+        comp = (g & np.uint64(3)).astype(np.int64)[:, None]
+        pick = np.where(comp == 0, x[0], np.where(comp == 1, x[1], np.where(comp == 2, x[2], x[3])))
+        return _u32_to_uniform(pick.astype(np.uint32))
+
     def uniform(self, shape) -> np.ndarray:
         self.log.append(("u", tuple(shape)))
-        x0, _, _, _ = self._block(shape)
-        return _u32_to_uniform(x0)
+        return self._uniform_block(shape)
 
     def normal(self, shape) -> np.ndarray:
         self.log.append(("n", tuple(shape)))
@@ -178,8 +190,7 @@ class PhiloxStream:
         return idx
 
     def uniform_silent(self, shape):
-        x0, _, _, _ = self._block(shape)
-        return _u32_to_uniform(x0)
+        return self._uniform_block(shape)
 
     def exhausted_cat(self) -> bool:
         return True

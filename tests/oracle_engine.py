@@ -107,7 +107,7 @@ class OracleEngine:
         s.done()
         return tuple(self._t(x) for x in out)
 
-    def cd_step(self, rbm, data, lr, mom, cd_k, rng):
+    def cd_step(self, rbm, data, lr, mom, cd_k, rng, next_data=None):       # the prefetch hint changes no result
         st = self._state(rbm, True)
         s = _Src(rng)
         stats = O.cd_statistics(st, _np(data), cd_k, s)

@@ -531,3 +531,46 @@ def test_device_loader_feeds_training_from_hbm(tmp_path):
         assert emb.is_cuda and emb.shape == (len(va.dataset), 64) and feats["labels"].numel() == emb.size(0)
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.parametrize("V,H,B", [(10000, 1500, 64), (2048, 512, 40), (8192, 1024, 100)])
+def test_next_batch_prefetch_is_bit_identical_and_guards_against_stale_data(V, H, B, _native):
+    """RBM.train_epoch(next_data=): the operand forms of the following batch are prepared by extra blocks of the
+    first negative-phase launch.  Same bits as the plain sequence; a batch modified in place, a different tensor or a
+    different shape is prepared again."""
+    from imdbn import engine as E
+    g = np.random.default_rng(9)
+    Xs = [P.T((g.random((B, V), dtype=F32) > 0.8).astype(F32), DEV) for _ in range(5)]
+    Xs[3] = P.T(g.random((B, V), dtype=F32), DEV)                     # an inexact batch: three operand terms
+    r1, _, _ = _mk(V, H, None, seed=6)
+    r2, _, _ = _mk(V, H, None, seed=6)
+    with E.use_rng(E.PhiloxRng(seed=4)):
+        l1 = [float(r1.train_epoch(x, 0, 1, CD=1)) for x in Xs]
+    d = _native._desc(r2, True)
+    ok = _native.prefetch_ok(d, B)
+    assert ok                                          # aligned weight rows: the fused K2 carries the prefetch blocks
+    with E.use_rng(E.PhiloxRng(seed=4)):
+        l2 = []
+        for i, x in enumerate(Xs):
+            nxt = Xs[i + 1] if i + 1 < len(Xs) else None
+            if i == 1 and nxt is not None:
+                nxt = nxt.clone()                                     # hint a DIFFERENT tensor than the one passed next
+            l2.append(float(r2.train_epoch(x, 0, 1, CD=1, next_data=nxt)))
+            if i == 2:
+                Xs[3].mul_(1.0)                                       # in-place op: version bump -> prefetched forms are dropped
+            assert (len(_native._pf) == 1) == (ok and nxt is not None)
+    assert l1 == l2
+    for k in P.KEYS:
+        assert torch.equal(getattr(r1, k).data if hasattr(getattr(r1, k), "data") else getattr(r1, k),
+                           getattr(r2, k).data if hasattr(getattr(r2, k), "data") else getattr(r2, k)), k
+    # the hint really is consumed: with the prefetched tensor overwritten through a raw copy (no version bump) the
+    # step uses the stale forms -- documents the caller's contract rather than a desirable property
+    if ok:
+        r3, _, _ = _mk(V, H, None, seed=6)
+        r4, _, _ = _mk(V, H, None, seed=6)
+        a, b = Xs[0].clone(), Xs[1].clone()
+        with E.use_rng(E.PhiloxRng(seed=4)):
+            r3.train_epoch(a, 0, 1, CD=1, next_data=b)
+            assert len(_native._pf) == 1
+            _native.set_option("no_prefetch", 0)                      # clears the engine's prefetch state
+            assert len(_native._pf) == 0

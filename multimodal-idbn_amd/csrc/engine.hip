@@ -29,6 +29,8 @@ bool g_no_fused_up = false;
 int g_k4_rows = 0;          // tuning: batch rows per chain-kernel block (0 = automatic)
 int g_no_rank_loop = 0;     // testing: one update-kernel launch per gathered rank block
 int g_no_chain_kernel = 0;  // testing: run chains as one launch per half step
+int g_no_rank_acc = 0;   // testing: tile-wise rank loop (k3_body_ranks) even when the accumulating form applies
+int g_min_rank_loop = 2;  // apply_factors: rank blocks from which the single-launch rank loop is used (1 block: the plain update kernel, 46 vs 60 us)
 int g_no_prefetch = 0;   // testing: ignore imdbn_cd_opts.next_data
 int g_no_bits = 0;  // testing: never use the bit-packed hidden operand
 int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
@@ -744,6 +746,8 @@ int imdbn_set_option(const char* name, int value) {
     else if (!strcmp(name, "chain_rows")) { if (value < 0 || value > 16) return fail(IMDBN_E_INVALID, "chain_rows must be in [0, 16]"); g_k4_rows = value; }
     else if (!strcmp(name, "no_bits")) g_no_bits = value;
     else if (!strcmp(name, "no_prefetch")) g_no_prefetch = value;
+    else if (!strcmp(name, "no_rank_acc")) g_no_rank_acc = value;
+    else if (!strcmp(name, "min_rank_loop")) g_min_rank_loop = value;
     else if (!strcmp(name, "dbg")) g_dbg = value;
     else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
     else if (!strcmp(name, "no_fused_up")) g_no_fused_up = value != 0;
@@ -1008,14 +1012,17 @@ int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n
     const int brows = nh >= 2 ? 1 : 2;
     // all rank blocks inside one launch (the weights move once) when the visible operands need <= 4 plane slices
     // (measured at 10000 x 1500: 2 / 4 / 8 blocks 85 / 119 / 189 us here, 83 / 140 / 251 us as one launch per block)
-    if (n_ranks >= 3 && !g_no_rank_loop && f.vneg_terms == 1) {
+    if (n_ranks >= g_min_rank_loop && !g_no_rank_loop && f.vneg_terms == 1) {
         f.vpos = (const bf16_t*)at(L.vis_tr[0], 0); f.vpos_flag = (const int*)at(L.flags, 0);
         f.hpos = (const bf16_t*)at(L.hid_tr[0], 0);
         f.vneg = (const bf16_t*)at(L.vis_tr[1], 0); f.hneg = (const bf16_t*)at(L.hid_tr[1], 0);
         RankLoopArgs rl{n_ranks, (int64_t)(rank_stride / 2)};
         dim3 g(nh, cdiv(nv, tpb) + brows);
-        if (c.rt == 3) hipLaunchKernelGGL((assoc_update_planes_ranks<3>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows);
-        else           hipLaunchKernelGGL((assoc_update_planes_ranks<1>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows);
+        const bool acc = tpb <= 4 && !g_no_rank_acc;       // rank loop outside the tile loop: hidden planes staged once per rank
+        if (c.rt == 3) { if (acc) hipLaunchKernelGGL((assoc_update_planes_ranks<3, true>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows);
+                         else     hipLaunchKernelGGL((assoc_update_planes_ranks<3, false>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows); }
+        else           { if (acc) hipLaunchKernelGGL((assoc_update_planes_ranks<1, true>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows);
+                         else     hipLaunchKernelGGL((assoc_update_planes_ranks<1, false>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows); }
         HIPCHK(hipGetLastError());
         return 0;
     }

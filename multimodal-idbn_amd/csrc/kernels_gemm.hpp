@@ -1068,7 +1068,135 @@ __device__ __forceinline__ void k3_body_ranks(const AssocPlanesArgs& a, const Ra
     }
 }
 
+// Rank loop OUTSIDE the tile loop (tiles_per_block <= 4): a rank's hidden planes are staged once and meet all of the
+// block's visible tiles (one accumulator set per tile: 4 x 64 registers, AGPRs), the visible slices of the next tile
+// are staged while the current one multiplies (two slot pairs when a tile needs <= 2 planes: binary data), and the
+// weights are read-modify-written in a second phase, once.  The tile-wise order above restages 96 KB of hidden planes
+// for every (tile, rank) pair with nothing to overlap them with: 8 rank blocks cost 189 us there.
 template <int HT>
+__device__ __forceinline__ void k3_body_ranks_acc(const AssocPlanesArgs& a, const RankLoopArgs& rl, char* smem, int bx, int by,
+                                                  int tiles_per_block, int nap, int nan_) {
+    const int P = nap + nan_;                                       // planes per tile and rank: 2 or 4
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, kh = l >> 5;
+    const int h0 = bx * 128;
+    const int tile0 = by * tiles_per_block;
+    const int n_vtiles = (a.V + 127) / 128;
+    const int n_my = min(tiles_per_block, n_vtiles - tile0);
+    const int colc = min(h0 + 4 * r, a.H - 4);
+    const bool cok = (h0 + 4 * r) < a.H;
+    const bool n_pow2 = (__float_as_uint(a.n) & 0x7fffffu) == 0u;
+    const float inv_n = 1.0f / a.n;
+    char* sHp = smem;
+    char* sHn = smem + 3 * K3_PLANE;
+    char* sV = smem + K3_VIS0 + w * (4 * K3_SLICE);
+    const uint32_t sV_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sV);
+    const uint32_t sH_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+    const bool dbl = P <= 2;                                        // two slot pairs: stage tile t+1 under the MFMAs of tile t
+
+    auto dma_hidden = [&](int rk) {                                  // 2 x HT planes of rank rk, all four waves: 8 HT ops per wave
+        const int64_t ro = (int64_t)rk * rl.stride;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int tb = 0; tb < HT; ++tb)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = 4 * w + jj, i = 64 * j + l, lrow = i >> 3, pos = i & 7;
+                    const int row = 4 * (lrow & 31) + (lrow >> 5), c = pos ^ ((lrow >> 1) & 7);
+                    const bf16_t* src = (ph ? a.hneg : a.hpos) + ro + tb * a.hts + (int64_t)min(h0 + row, a.H - 1) * a.Bp + 8 * c;
+                    k3_dma16(src, sH_lds + (3 * ph + tb) * K3_PLANE + j * 1024);
+                }
+    };
+    // this wave's visible slices of (rank rk, rows v0w ..): planes 0..1 into slots base, base+1 (dbl) or planes 0..3 into slots 0..3;
+    // always 8 (dbl) or 16 ops
+    auto dma_slices = [&](int rk, int v0w, int base) {
+        const int64_t ro = (int64_t)rk * rl.stride;
+        const int np = dbl ? 2 : 4;
+        for (int p = 0; p < np; ++p) {
+            const int pl = min(p, P - 1);
+            const bf16_t* src = (pl < nap ? a.vpos + pl * a.vts : a.vneg + (pl - nap) * a.vts) + ro;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = l + 64 * q, row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
+                k3_dma16(src + (int64_t)min(v0w + row, a.V - 1) * a.Bp + 8 * c, sV_lds + (base + p) * K3_SLICE + q * 1024);
+            }
+        }
+    };
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[it][t][i] = 0.f;
+
+    for (int rk = 0; rk < rl.n_ranks; ++rk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                             // every wave is done with the previous rank's planes and slices
+        dma_hidden(rk);
+        dma_slices(rk, tile0 * 128 + 32 * w, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (it < n_my) {                                         // block-uniform
+                const int base = dbl ? 2 * (it & 1) : 0;
+                if (dbl) {
+                    if (it + 1 < n_my) {
+                        dma_slices(rk, (tile0 + it + 1) * 128 + 32 * w, 2 * ((it + 1) & 1));      // its previous readers (tile it-1) are done: same wave
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                           // everything but those 8 ops has landed
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                } else {
+                    if (it > 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // tile it-1's LDS reads are done
+                        dma_slices(rk, (tile0 + it) * 128 + 32 * w, 0);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (it == 0) __syncthreads();                        // the hidden planes (staged by all four waves) are complete
+                for (int p = 0; p < P; ++p)
+                    k3_mfma_wave<HT>(acc[it], p < nap ? sHp : sHn, sV + (base + p) * K3_SLICE, r, kh);
+                if (dbl) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the slot pair is restaged two tiles later
+            }
+        }
+    }
+    // phase 2: one read-modify-write of the block's weight tiles
+    float4 wc[16], mc[16];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (it < n_my) {
+            const int v0 = (tile0 + it) * 128;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = min(v0 + 32 * w + mfma_row(reg, l), a.V - 1);
+                const int64_t idx = (int64_t)row * a.ldw + colc;
+                wc[reg] = *reinterpret_cast<const float4*>(a.W + idx);
+                mc[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = v0 + 32 * w + mfma_row(reg, l);
+                if (row < a.V && cok) {
+                    const float4 d = make_float4(acc[it][0][reg], acc[it][1][reg], acc[it][2][reg], acc[it][3][reg]);
+                    const int64_t idx = (int64_t)row * a.ldw + h0 + 4 * r;
+                    const float4 w0 = wc[reg];
+                    float4 m = mc[reg];
+                    const float gx = n_pow2 ? d.x * inv_n : d.x / a.n, gy = n_pow2 ? d.y * inv_n : d.y / a.n;
+                    const float gz = n_pow2 ? d.z * inv_n : d.z / a.n, gw = n_pow2 ? d.w * inv_n : d.w / a.n;
+                    m.x = m.x * a.mom; m.x = m.x + a.lr * (gx - a.wd * w0.x);        // rbm.py:212
+                    m.y = m.y * a.mom; m.y = m.y + a.lr * (gy - a.wd * w0.y);
+                    m.z = m.z * a.mom; m.z = m.z + a.lr * (gz - a.wd * w0.z);
+                    m.w = m.w * a.mom; m.w = m.w + a.lr * (gw - a.wd * w0.w);
+                    *reinterpret_cast<float4*>(a.Wm + idx) = m;
+                    *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
+                }
+            }
+        }
+    }
+}
+
+// ACC = rank loop outside the tile loop (k3_body_ranks_acc; needs tiles_per_block <= 4); one body per kernel
+template <int HT, bool ACC>
 __global__ __launch_bounds__(256, 1) void assoc_update_planes_ranks(const AssocPlanesArgs a, const RankLoopArgs rl, int tiles_per_block,
                                                                     const BiasArgs bias, int bias_rows) {
     __shared__ __attribute__((aligned(16))) char smem[K3_LDS_BYTES];
@@ -1099,7 +1227,8 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes_ranks(const AssocP
         for (int rk = 0; rk < rl.n_ranks; ++rk)
             nap = max(nap, operand_terms(a.vpos_flag + rk * (rl.stride / 2), ncbv, a.Bp / 8, (tile0 * 128) / 64, (tile0 + tiles_per_block) * 2, 0));
     }
-    k3_body_ranks<HT>(a, rl, smem, bx, by, tiles_per_block, nap, a.vneg_terms);
+    if constexpr (ACC) k3_body_ranks_acc<HT>(a, rl, smem, bx, by, tiles_per_block, nap, a.vneg_terms);
+    else               k3_body_ranks<HT>(a, rl, smem, bx, by, tiles_per_block, nap, a.vneg_terms);
 }
 
 template <int MODE, int HT, int PASS>

@@ -12,7 +12,7 @@ typedef uint16_t bf16_t;     // raw bf16 bits in memory
 constexpr int WAVE = 64;
 
 // ------------------------------------------------------------------------------------------
-// Philox-4x32-10.  counter = (column, global row [normal] or global row >> 2 [uniform], draw_lo, draw_hi), key = seed.
+// Philox-4x32-10.  counter = (column, global row >> 1 [normal] or global row >> 2 [uniform], draw_lo, draw_hi), key = seed.
 // numpy twin: oracle/draws.py:PhiloxStream.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
@@ -85,12 +85,39 @@ __device__ __forceinline__ void draw_uniform_rows(const DrawSrc& s, int b0, int 
     for (int i = 0; i < R; ++i) u[i] = draw_uniform(s, min(b0 + i, bmax), n);
 }
 
+// Normal draws (Box-Muller): the two rows of a global row PAIR share one Philox block (counter row = global row >> 1;
+// the even row takes outputs x,y, the odd row z,w).  In the chain kernels Philox was ~80 % of the element-wise work.
+__device__ __forceinline__ float normal_from(uint32_t a, uint32_t b) {
+    const float u1 = ((float)(a >> 8) + 1.0f) * 5.9604644775390625e-08f;
+    const float u2 = (float)(b >> 8) * 5.9604644775390625e-08f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+__device__ __forceinline__ uint4 draw_block2(const DrawSrc& s, uint64_t grow, int n) {
+    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)(grow >> 1), (uint32_t)s.draw, (uint32_t)(s.draw >> 32)),
+                         make_uint2((uint32_t)s.seed, (uint32_t)(s.seed >> 32)));
+}
 __device__ __forceinline__ float draw_normal(const DrawSrc& s, int b, int n) {
     if (s.tape) return s.tape[(int64_t)b * s.N + n];
-    const uint4 x = draw_block(s, b, n);
-    const float u1 = ((float)(x.x >> 8) + 1.0f) * 5.9604644775390625e-08f;
-    const float u2 = (float)(x.y >> 8) * 5.9604644775390625e-08f;
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    const uint64_t g = (uint64_t)(s.row0 + b);
+    const uint4 x = draw_block2(s, g, n);
+    return (g & 1) ? normal_from(x.z, x.w) : normal_from(x.x, x.y);
+}
+// rows b0, b0+1 (clamped to bmax) of column n: one Philox block when they are a global pair
+__device__ __forceinline__ void draw_normal_rows2(const DrawSrc& s, int b0, int bmax, int n, float (&z)[2]) {
+    if (s.tape) {
+        z[0] = s.tape[(int64_t)min(b0, bmax) * s.N + n];
+        z[1] = s.tape[(int64_t)min(b0 + 1, bmax) * s.N + n];
+        return;
+    }
+    const uint64_t g0 = (uint64_t)(s.row0 + b0);
+    if ((g0 & 1) == 0 && b0 + 1 <= bmax) {
+        const uint4 x = draw_block2(s, g0, n);
+        z[0] = normal_from(x.x, x.y);
+        z[1] = normal_from(x.z, x.w);
+        return;
+    }
+    z[0] = draw_normal(s, min(b0, bmax), n);
+    z[1] = draw_normal(s, min(b0 + 1, bmax), n);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     for (int i = tid; i < at * K4_ROWS * HK; i += K4_THREADS) hact[i] = 0;          // pad columns and rows >= RB stay zero for the whole chain
     __syncthreads();
 
+    const int RP = (RB + 1) / 2;                                  // row pairs of the block
     for (int t = 0; t < a.n_steps; ++t) {
         const ChainRec r = a.recs[t];
         const bool sample_h = (r.flags & 1) != 0, clamp = (r.flags & 8) != 0, last = t == a.n_steps - 1;
@@ -227,14 +228,23 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
         __syncthreads();
         {
             const DrawSrc nz = k4_src(a, r.noise_h, a.H), un = k4_src(a, r.uni_h, a.H);
-            for (int i = tid; i < RB * a.H; i += K4_THREADS) {
-                const int row = i / a.H, col = i - row * a.H, bd = min(b0 + row, a.B - 1);
-                float x = stage[row * SP + col] + a.hid_bias[col];
-                if (T != 1.0f) x = x / T;
-                if (r.sigma > 0.f) x = x + draw_normal(nz, bd, col) * r.sigma;
-                float p = sigmoidf_ref(x);
-                if (sample_h) p = (p > draw_uniform(un, bd, col)) ? 1.f : 0.f;
-                k4_put<NW>(hact, HK, row, col, (b0 + row < a.B) ? p : 0.f, sample_h);
+            // thread = (row pair, column): the pair's draws come from one Philox block each (common.hpp)
+            for (int i = tid; i < RP * a.H; i += K4_THREADS) {
+                const int pr = i / a.H, col = i - pr * a.H;
+                float z2[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};
+                if (r.sigma > 0.f) draw_normal_rows2(nz, b0 + 2 * pr, a.B - 1, col, z2);
+                if (sample_h) draw_uniform_rows<2>(un, b0 + 2 * pr, a.B - 1, col, u2);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int row = 2 * pr + hf;
+                    if (row >= RB) break;
+                    float x = stage[row * SP + col] + a.hid_bias[col];
+                    if (T != 1.0f) x = x / T;
+                    if (r.sigma > 0.f) x = x + z2[hf] * r.sigma;
+                    float p = sigmoidf_ref(x);
+                    if (sample_h) p = (p > u2[hf]) ? 1.f : 0.f;
+                    k4_put<NW>(hact, HK, row, col, (b0 + row < a.B) ? p : 0.f, sample_h);
+                }
             }
         }
         __syncthreads();
@@ -244,30 +254,40 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
         __syncthreads();
         {
             const DrawSrc nz = k4_src(a, r.noise_v, a.V), un = k4_src(a, r.uni_v, a.V);
-            for (int i = tid; i < RB * a.V; i += K4_THREADS) {
-                const int row = i / a.V, col = i - row * a.V, b = b0 + row, bd = min(b, a.B - 1);
-                float x = stage[row * SP + col] + a.vis_bias[col];
-                if (T != 1.0f) x = x / T;
-                if (r.sigma > 0.f) x = x + draw_normal(nz, bd, col) * r.sigma;
-                if (gwd > 0 && col >= gs0 && col < gs0 + gwd) {              // softmax group: logits now, the rest below
-                    glog[row * GW + (col - gs0)] = x;
-                    continue;
+            for (int i = tid; i < RP * a.V; i += K4_THREADS) {
+                const int pr = i / a.V, col = i - pr * a.V;
+                const bool in_group = gwd > 0 && col >= gs0 && col < gs0 + gwd;
+                float z2[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};
+                if (r.sigma > 0.f) draw_normal_rows2(nz, b0 + 2 * pr, a.B - 1, col, z2);
+                if (vmode != 0 && !in_group) draw_uniform_rows<2>(un, b0 + 2 * pr, a.B - 1, col, u2);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int row = 2 * pr + hf;
+                    if (row >= RB) break;
+                    const int b = b0 + row, bd = min(b, a.B - 1);
+                    float x = stage[row * SP + col] + a.vis_bias[col];
+                    if (T != 1.0f) x = x / T;
+                    if (r.sigma > 0.f) x = x + z2[hf] * r.sigma;
+                    if (in_group) {                                          // softmax group: logits now, the rest below
+                        glog[row * GW + (col - gs0)] = x;
+                        continue;
+                    }
+                    float p = sigmoidf_ref(x);
+                    if (pull_on && col < a.Dz) p = (1.0f - r.eta) * p + r.eta * a.mu[(int64_t)bd * a.ldmu + col];
+                    const float m = clamp ? a.mask[(int64_t)bd * a.ldk + col] : 0.f;
+                    const float kn = clamp ? a.vk[(int64_t)bd * a.ldk + col] : 0.f;
+                    const float mixed = clamp ? (p * (1.0f - m) + kn * m) : p;
+                    float v;
+                    if (vmode == 0) v = mixed;
+                    else {
+                        const float u = u2[hf];
+                        if (vmode == 1) { const float smp = (p > u) ? 1.f : 0.f; v = clamp ? (smp * (1.0f - m) + kn * m) : smp; }
+                        else v = (mixed > u) ? 1.f : 0.f;
+                    }
+                    if (b >= a.B) v = 0.f;
+                    k4_put<NW>(vact, VK, row, col, v, false);
+                    if (last && b < a.B) a.state[(int64_t)b * a.lds + col] = v;
                 }
-                float p = sigmoidf_ref(x);
-                if (pull_on && col < a.Dz) p = (1.0f - r.eta) * p + r.eta * a.mu[(int64_t)bd * a.ldmu + col];
-                const float m = clamp ? a.mask[(int64_t)bd * a.ldk + col] : 0.f;
-                const float kn = clamp ? a.vk[(int64_t)bd * a.ldk + col] : 0.f;
-                const float mixed = clamp ? (p * (1.0f - m) + kn * m) : p;
-                float v;
-                if (vmode == 0) v = mixed;
-                else {
-                    const float u = draw_uniform(un, bd, col);
-                    if (vmode == 1) { const float smp = (p > u) ? 1.f : 0.f; v = clamp ? (smp * (1.0f - m) + kn * m) : smp; }
-                    else v = (mixed > u) ? 1.f : 0.f;
-                }
-                if (b >= a.B) v = 0.f;
-                k4_put<NW>(vact, VK, row, col, v, false);
-                if (last && b < a.B) a.state[(int64_t)b * a.lds + col] = v;
             }
         }
         if (gwd > 0) {

@@ -202,6 +202,17 @@ __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, 
     float lsum = 0.f;
     csum = 0.f;
     if (vmode != 0) draw_uniform_rows<R>(a.uni, b0, a.B - 1, cc, us);      // draws for padded rows / columns: clamped, discarded
+    float nzs[R];
+    if constexpr (EX) {
+        if (a.sigma > 0.f) {
+#pragma unroll
+            for (int j = 0; j < R / 2; ++j) {
+                float z[2];
+                draw_normal_rows2(a.noise, b0 + 2 * j, a.B - 1, cc, z);
+                nzs[2 * j] = z[0]; nzs[2 * j + 1] = z[1];
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int b = b0 + i;
@@ -210,7 +221,7 @@ __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, 
         float x = xs[i] + bias;
         if constexpr (EX) {
             if (a.T != 1.0f) x = x / a.T;
-            if (a.sigma > 0.f) x = x + draw_normal(a.noise, bd, cc) * a.sigma;
+            if (a.sigma > 0.f) x = x + nzs[i] * a.sigma;
         }
         float p = sigmoidf_ref(x);
         if (pull) p = (1.0f - a.eta) * p + a.eta * sd.mu[i];

@@ -115,8 +115,8 @@ class PhiloxStream:
     one per draw) has element ``(b, n)`` generated from
 
         key     = (seed_lo, seed_hi)
-        normal : counter = (n, row0 + b, s_lo, s_hi) -> ``x[0..3]``;
-                 sqrt(-2 ln u1) * cos(2 pi u2),  u1 = ((x[0]>>8)+1) * 2^-24, u2 = (x[1]>>8) * 2^-24
+        normal : counter = (n, (row0 + b) >> 1, s_lo, s_hi) -> ``x[0..3]``; (a, c) = (x[0], x[1]) for an even global
+                 row, (x[2], x[3]) for an odd one;  sqrt(-2 ln u1) * cos(2 pi u2),  u1 = ((a>>8)+1) * 2^-24, u2 = (c>>8) * 2^-24
         uniform: counter = (n, (row0 + b) >> 2, s_lo, s_hi) -> ``x[0..3]``;  (x[(row0 + b) & 3] >> 8) * 2^-24
                  (the four rows of a global 4-row group share one Philox block: csrc/common.hpp draw_uniform_rows)
 
@@ -130,15 +130,6 @@ class PhiloxStream:
         self.offset = int(offset)
         self.row0 = int(row0)
         self.log = []
-
-    def _block(self, shape):
-        B, N = int(shape[0]), int(shape[1])
-        s = self.offset
-        self.offset += 1
-        rows = (np.arange(B, dtype=np.uint64) + np.uint64(self.row0)).astype(np.uint32)[:, None]
-        cols = np.arange(N, dtype=np.uint32)[None, :]
-        return philox4x32_10(cols, rows, np.uint32(s & 0xFFFFFFFF), np.uint32((s >> 32) & 0xFFFFFFFF),
-                             self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
 
     def _uniform_block(self, shape):
         B, N = int(shape[0]), int(shape[1])
@@ -158,7 +149,16 @@ class PhiloxStream:
 
     def normal(self, shape) -> np.ndarray:
         self.log.append(("n", tuple(shape)))
-        x0, x1, _, _ = self._block(shape)
+        B, N = int(shape[0]), int(shape[1])
+        s = self.offset
+        self.offset += 1
+        g = np.arange(B, dtype=np.uint64) + np.uint64(self.row0)
+        cols = np.arange(N, dtype=np.uint32)[None, :]
+        x = philox4x32_10(cols, (g >> np.uint64(1)).astype(np.uint32)[:, None], np.uint32(s & 0xFFFFFFFF),
+                          np.uint32((s >> 32) & 0xFFFFFFFF), self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+        odd = (g & np.uint64(1)).astype(bool)[:, None]
+        x0 = np.where(odd, x[2], x[0]).astype(np.uint32)
+        x1 = np.where(odd, x[3], x[1]).astype(np.uint32)
         u1 = ((x0 >> np.uint32(8)).astype(np.float32) + np.float32(1.0)) * np.float32(2.0 ** -24)
         u2 = _u32_to_uniform(x1)
         r = np.sqrt(np.float32(-2.0) * np.log(u1)).astype(np.float32)

@@ -11,8 +11,9 @@ from imdbn.models import RBM
 dev = torch.device("cuda:0")
 eng = E.get_hip_engine()
 E.manual_seed(3)
+GROUPS = None if os.environ.get("NO_GROUP") else [(500, 532)]
 for B in (64, 256):
-    jr = RBM(532, 256, 0.04, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=[(500, 532)]).to(dev)
+    jr = RBM(532, 256, 0.04, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=GROUPS).to(dev)
     y = torch.eye(32, device=dev)[torch.randint(0, 32, (B,), device=dev)]
     vk = torch.zeros(B, 532, device=dev); km = torch.zeros(B, 532, device=dev)
     vk[:, 500:] = y; km[:, 500:] = 1

@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--ksplit-up", type=int, default=0)
     ap.add_argument("--ksplit-down", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
+    ap.add_argument("--dp-full-planes", action="store_true", help="factor exchange: send the data plane as bf16 planes, not bits")
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand train_epoch the following batch (next_data=)")
     ap.add_argument("--force-dp", action="store_true", help="take the stats/all-reduce/apply path even with one rank")
     ap.add_argument("--no-k3-events", action="store_true", help="do not bracket K3 with HIP events in the timed region")
@@ -142,7 +143,7 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     if world > 1 or args.force_dp:
-        E.dp.enable(force=args.force_dp, mode=args.dp_mode)
+        E.dp.enable(force=args.force_dp, mode=args.dp_mode, binary_data=not args.dp_full_planes)   # the synthetic batches are 0/1 images
 
     torch.manual_seed(0)
     rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
@@ -175,7 +176,7 @@ def main():
             raise
         print(f"[bench] rank {rank}: factor exchange failed ({type(e).__name__}: {e}); using the all-reduce exchange", file=sys.stderr, flush=True)
         args.dp_mode = "allreduce"
-        E.dp.enable(force=args.force_dp, mode="allreduce")
+        E.dp.enable(force=args.force_dp, mode="allreduce", binary_data=not args.dp_full_planes)
         for i in range(args.warmup):
             step(i)
         sync()
@@ -211,7 +212,8 @@ def main():
             "config": {"workload": "BASELINE configs[1] layer 1: RBM 10000<->1500 train_epoch, CD-1, batch 64 per GPU, "
                                    "fp32 master weights, lr 0.1 wd 1e-4 mom 0.5",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "dp_exchange": (args.dp_mode if (world > 1 or args.force_dp) else None),
+                       "dp_exchange": ((args.dp_mode + ("" if args.dp_mode != "factors" else (" (wire form: sample as bits)" if args.dp_full_planes else " (wire form: data and sample as bits)")))
+                                       if (world > 1 or args.force_dp) else None),
                        "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
                        "final_loss": float(loss)},
             "global_steps_per_s": args.steps / dt,

@@ -198,6 +198,17 @@ int    imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, in
                                int rows_per_rank, int global_B, const imdbn_cd_opts* opts, float* loss_out,
                                imdbn_stream_t stream);
 
+/* Wire form of the factor block: the negative visible sample (always 0/1) and, with binary_data != 0, the data plane
+ * travel as 1 bit per element (7.0 -> 5.8 / 2.1 MB per rank at 10000 x 1500).  pack: one full block (as left by
+ * imdbn_rbm_cd_factors) -> one compact block of imdbn_factor_compact_bytes(); all-gather the compact blocks;
+ * unpack: n_ranks compact blocks -> n_ranks full blocks for imdbn_rbm_apply_factors.  A plane that is declared binary
+ * and is not poisons the update with NaN (fails loudly).  All pointers / strides 16-B aligned; a compact buffer must be
+ * zero-initialised once before its first use. */
+int    imdbn_factor_compact_bytes(int V, int H, int B, int binary_data, size_t* bytes);
+int    imdbn_rbm_pack_factors(int V, int H, int B, int binary_data, const void* block, void* compact, imdbn_stream_t stream);
+int    imdbn_rbm_unpack_factors(int V, int H, int B, int binary_data, const void* compact, size_t compact_stride, int n_ranks,
+                                void* gathered, size_t full_stride, imdbn_stream_t stream);
+
 /* ---- K4: conditional chains (rbm.py:240-400) -------------------------------------------- */
 /* v0 = v_known*mask + (1-mask)*U (init_uniform=1) or v_known (0); then n_steps steps; out_v[B][V].
  * mu (nullable) is the [B][Dz] pull target of rbm.py:359-363. */

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -962,6 +963,60 @@ int imdbn_factor_block(int V, int H, int B, size_t* offset, size_t* bytes) {
 static bool factor_mode_ok(const imdbn_rbm_desc* d, int B, bool with_momentum) {
     return B >= 1 && B <= 64 && d->H % 4 == 0 && d->H >= 4 && d->ldw % 4 == 0 && (((uintptr_t)d->W) & 15) == 0 &&
            (!with_momentum || (d->W_m && (((uintptr_t)d->W_m) & 15) == 0)) && d->n_groups == 0;
+}
+
+// offsets of the wire form (kernels_ew.hpp FactorWireArgs) for an (V, H, B) factor block
+static FactorWireArgs wire_layout(int V, int H, int B, int binary, size_t* compact_bytes) {
+    char* fake = reinterpret_cast<char*>((uintptr_t)1 << 30);          // only differences of the carved pointers are used
+    const Layout L = make_layout(V, H, B, fake);
+    const char* fb = fake + L.fb_off;
+    FactorWireArgs w;
+    memset(&w, 0, sizeof(w));
+    w.V = V; w.Bp = L.Bp; w.binary = binary ? 1 : 0;
+    w.f_vpos = (size_t)((const char*)L.vis_tr[0] - fb);
+    w.f_vneg = (size_t)((const char*)L.vis_tr[1] - fb);
+    w.f_cs_hpos = (size_t)((const char*)L.cs_hpos - fb);
+    w.head_bytes = w.f_vpos;                                            // flags .. loss_part precede the visible planes
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t bits = up((size_t)V * L.Bp / 8);
+    w.c_vneg = w.head_bytes;
+    w.c_vpos = w.c_vneg + bits;
+    w.c_bad = w.c_vpos + (binary ? bits : up((size_t)3 * V * L.Bp * 2));
+    if (compact_bytes) *compact_bytes = w.c_bad + 256;
+    return w;
+}
+
+int imdbn_factor_compact_bytes(int V, int H, int B, int binary_data, size_t* bytes) {
+    if (V <= 0 || H <= 0 || B <= 0 || !bytes) return fail(IMDBN_E_INVALID, "factor_compact_bytes: bad argument");
+    (void)wire_layout(V, H, B, binary_data, bytes);
+    return 0;
+}
+
+int imdbn_rbm_pack_factors(int V, int H, int B, int binary_data, const void* block, void* compact, imdbn_stream_t stream) {
+    if (V <= 0 || H <= 0 || B <= 0 || !block || !compact || (((uintptr_t)block | (uintptr_t)compact) & 15))
+        return fail(IMDBN_E_INVALID, "pack_factors: bad argument (blocks must be 16-B aligned)");
+    FactorWireArgs w = wire_layout(V, H, B, binary_data, nullptr);
+    w.src = (const char*)block; w.dst = (char*)compact; w.n_ranks = 1;
+    static std::atomic<int> epoch{0};        // any value >= 1 that changes from call to call (a stale `bad` mark must not match;
+    w.epoch = epoch.fetch_add(1) % 1000000 + 1;   //  the caller zero-initialises a fresh compact buffer)
+    hipLaunchKernelGGL(factor_pack, dim3(std::min(1024, cdiv((int)(w.head_bytes / 16), 256))), dim3(256), 0, S(stream), w);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int imdbn_rbm_unpack_factors(int V, int H, int B, int binary_data, const void* compact, size_t compact_stride, int n_ranks,
+                             void* gathered, size_t full_stride, imdbn_stream_t stream) {
+    if (V <= 0 || H <= 0 || B <= 0 || !compact || !gathered || n_ranks < 1 || (((uintptr_t)compact | (uintptr_t)gathered | compact_stride | full_stride) & 15))
+        return fail(IMDBN_E_INVALID, "unpack_factors: bad argument (blocks and strides must be 16-B aligned)");
+    size_t cb = 0;
+    FactorWireArgs w = wire_layout(V, H, B, binary_data, &cb);
+    size_t off = 0, fbytes = 0;
+    CHK(imdbn_factor_block(V, H, B, &off, &fbytes));
+    if (compact_stride < cb || full_stride < fbytes) return fail(IMDBN_E_INVALID, "unpack_factors: strides smaller than the blocks");
+    w.src = (const char*)compact; w.dst = (char*)gathered; w.src_stride = compact_stride; w.dst_stride = full_stride; w.n_ranks = n_ranks;
+    hipLaunchKernelGGL(factor_unpack, dim3(std::min(512, cdiv((int)(w.head_bytes / 16), 256)), n_ranks), dim3(256), 0, S(stream), w);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 int imdbn_rbm_cd_factors(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B, const imdbn_cd_opts* o,

@@ -678,6 +678,93 @@ __global__ __launch_bounds__(256) void bias_update(const BiasArgs a) {
     bias_work(a, blockIdx.x, gridDim.x, sh);
 }
 
+// ---- wire form of the factor block (data-parallel factor exchange) ----------------------------------------------
+// The visible operands of a CD update are mostly bits: the negative visible state of train_epoch is a SAMPLE (always
+// 0/1) and layer-1 data are binary images (the caller says so: imdbn.engine.dp.enable(binary_data=True)).  A bf16
+// plane [V][Bp] then travels as V*Bp/8 bytes -- 16x smaller -- and the 7 MB block of a 10000 x 1500 layer becomes
+// ~2 MB (5.8 MB when only the sample is packed).  pack: full block -> compact block; unpack: N gathered compact
+// blocks -> N full blocks in the layout imdbn_rbm_apply_factors reads.  Everything before the visible planes
+// ("head": exactness map, hidden planes, column-sum and error partials) is copied verbatim.  A plane that claims to
+// be binary and is not sets the block's `bad` word; unpack then poisons the hidden-bias partials with NaN so that the
+// update fails loudly instead of silently dropping information.
+struct FactorWireArgs {
+    const char* src; char* dst;            // pack: one full block -> one compact block; unpack: gathered compact -> gathered full
+    size_t src_stride, dst_stride; int n_ranks;
+    size_t head_bytes;                     // multiple of 16
+    size_t f_vpos, f_vneg, f_cs_hpos;      // offsets inside the full block: vis_tr[0] (3 planes), vis_tr[1] (first plane), cs_hpos
+    size_t c_vneg, c_vpos, c_bad;          // offsets inside the compact block
+    int V, Bp, binary;
+    int epoch;                             // pack: a value that differs from call to call (no memset of the `bad` word needed)
+};
+
+// byte i of a bit plane <-> the 8 consecutive bf16 elements 8 i .. 8 i + 7 of the plane (one 16-B access per thread: the
+// first version moved 64 B per thread in four strided pieces and ran 30 us for a 4.5 MB job)
+__device__ __forceinline__ uint32_t pack8_bf16(const uint4 x, bool& bad) {
+    const uint32_t e[4] = {x.x, x.y, x.z, x.w};
+    uint32_t w = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = e[j] & 0xFFFFu, hi = e[j] >> 16;
+        bad |= (lo != 0u && lo != 0x3F80u) || (hi != 0u && hi != 0x3F80u);
+        w |= (lo ? 1u : 0u) << (2 * j);
+        w |= (hi ? 1u : 0u) << (2 * j + 1);
+    }
+    return w;
+}
+__device__ __forceinline__ uint4 unpack8_bf16(uint32_t w) {
+    uint32_t e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        e[j] = (((w >> (2 * j)) & 1u) ? 0x3F80u : 0u) | (((w >> (2 * j + 1)) & 1u) ? 0x3F800000u : 0u);
+    return make_uint4(e[0], e[1], e[2], e[3]);
+}
+
+// grid = (blocks, 1).  Trailer of the compact block: word 0 = `bad` (set to the call's epoch by any thread that meets a
+// non-binary value), word 1 = the epoch itself; the block is bad when the two agree (stale marks of earlier calls do not)
+__global__ __launch_bounds__(256) void factor_pack(const FactorWireArgs a) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthr = (int64_t)gridDim.x * 256;
+    for (int64_t i = tid; i < (int64_t)(a.head_bytes / 16); i += nthr)
+        reinterpret_cast<uint4*>(a.dst)[i] = reinterpret_cast<const uint4*>(a.src)[i];
+    const int64_t nb = (int64_t)a.V * a.Bp / 8;                       // bytes of a bit plane
+    bool bad = false;
+    for (int64_t i = tid; i < nb; i += nthr)
+        reinterpret_cast<uint8_t*>(a.dst + a.c_vneg)[i] = (uint8_t)pack8_bf16(reinterpret_cast<const uint4*>(a.src + a.f_vneg)[i], bad);
+    if (a.binary) {
+        for (int64_t i = tid; i < nb; i += nthr)
+            reinterpret_cast<uint8_t*>(a.dst + a.c_vpos)[i] = (uint8_t)pack8_bf16(reinterpret_cast<const uint4*>(a.src + a.f_vpos)[i], bad);
+    } else {
+        const int64_t n16 = (int64_t)3 * a.V * a.Bp * 2 / 16;
+        for (int64_t i = tid; i < n16; i += nthr)
+            reinterpret_cast<uint4*>(a.dst + a.c_vpos)[i] = reinterpret_cast<const uint4*>(a.src + a.f_vpos)[i];
+    }
+    if (bad) *reinterpret_cast<volatile int*>(a.dst + a.c_bad) = a.epoch;
+    if (tid == 0) reinterpret_cast<volatile int*>(a.dst + a.c_bad)[1] = a.epoch;
+}
+
+// grid = (blocks, n_ranks)
+__global__ __launch_bounds__(256) void factor_unpack(const FactorWireArgs a) {
+    const char* src = a.src + (size_t)blockIdx.y * a.src_stride;
+    char* dst = a.dst + (size_t)blockIdx.y * a.dst_stride;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthr = (int64_t)gridDim.x * 256;
+    const bool bad = reinterpret_cast<const int*>(src + a.c_bad)[0] == reinterpret_cast<const int*>(src + a.c_bad)[1];
+    for (int64_t i = tid; i < (int64_t)(a.head_bytes / 16); i += nthr) {
+        uint4 x = reinterpret_cast<const uint4*>(src)[i];
+        if (bad && i == (int64_t)(a.f_cs_hpos / 16)) x.x = 0x7FC00000u;       // NaN into the first hidden column-sum partial
+        reinterpret_cast<uint4*>(dst)[i] = x;
+    }
+    const int64_t nb = (int64_t)a.V * a.Bp / 8;
+    for (int64_t i = tid; i < nb; i += nthr)
+        reinterpret_cast<uint4*>(dst + a.f_vneg)[i] = unpack8_bf16(reinterpret_cast<const uint8_t*>(src + a.c_vneg)[i]);
+    if (a.binary) {
+        for (int64_t i = tid; i < nb; i += nthr)
+            reinterpret_cast<uint4*>(dst + a.f_vpos)[i] = unpack8_bf16(reinterpret_cast<const uint8_t*>(src + a.c_vpos)[i]);
+    } else {
+        const int64_t n16 = (int64_t)3 * a.V * a.Bp * 2 / 16;
+        for (int64_t i = tid; i < n16; i += nthr)
+            reinterpret_cast<uint4*>(dst + a.f_vpos)[i] = reinterpret_cast<const uint4*>(src + a.c_vpos)[i];
+    }
+}
+
 // ---- data-parallel split ------------------------------------------------------------------
 // packed = [dW V*H][dc H][db V][sumP+ H][sqerr 1][pad]
 struct PackArgs {

@@ -15,17 +15,22 @@ _group = None
 _enabled = False
 _force = False
 _mode = "factors"
+_binary = False
 
 
-def enable(group=None, force: bool = False, mode: str = "factors"):
+def enable(group=None, force: bool = False, mode: str = "factors", binary_data: bool = False):
     """Turn on data-parallel updates (requires an initialised torch.distributed).
 
     ``mode``: ``"factors"`` (default) all-gathers each rank's factor block (operand planes, column sums, error
     partials: ~7 MB per 64 rows at 10000 x 1500) and every rank runs the update kernel once per rank block;
     ``"allreduce"`` all-reduces the packed fp32 statistics (60 MB at that shape).  The factor exchange needs
     <= 64 rows per rank, 16-B aligned weight rows and no softmax groups; other cases take the all-reduce path.
-    ``force=True`` takes the data-parallel path even with a single rank (to exercise it on a one-GPU box)."""
-    global _group, _enabled, _force, _mode
+    ``force=True`` takes the data-parallel path even with a single rank (to exercise it on a one-GPU box).
+    ``binary_data=True``: the caller guarantees that the batches handed to ``RBM.train_epoch`` are exactly 0/1 (binary
+    images, e.g. ``imdbn.datasets.DeviceLoader``): their plane then crosses the wire as bits too (a batch that is not
+    binary turns the update into NaN rather than being silently truncated).  The negative visible sample always does."""
+    global _group, _enabled, _force, _mode, _binary
+    _binary = bool(binary_data)
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("imdbn.engine.dp.enable(): torch.distributed is not initialised")
@@ -38,8 +43,12 @@ def enable(group=None, force: bool = False, mode: str = "factors"):
 
 
 def disable():
-    global _group, _enabled, _force, _mode
-    _group, _enabled, _force, _mode = None, False, False, "factors"
+    global _group, _enabled, _force, _mode, _binary
+    _group, _enabled, _force, _mode, _binary = None, False, False, "factors", False
+
+
+def binary_data() -> bool:
+    return _binary
 
 
 def mode() -> str:

@@ -345,6 +345,43 @@ class HipEngine:
             buf = self._ws[key] = torch.empty(world, nb, dtype=torch.uint8, device=W.device)
         return buf
 
+    # wire form of the factor block (include/imdbn_engine.h): bit-packed visible planes
+    def compact_bytes(self, V, H, B, binary: bool) -> int:
+        nb = C.c_size_t(0)
+        N.check(self._lib.imdbn_factor_compact_bytes(int(V), int(H), int(B), int(bool(binary)), C.byref(nb)), "imdbn_factor_compact_bytes")
+        return int(nb.value)
+
+    def _wire_buffer(self, tag, rbm, B, world, binary) -> torch.Tensor:
+        W = rbm.W.data
+        key = (tag, W.device, W.shape[0], W.shape[1], B, world, bool(binary))
+        buf = self._ws.get(key)
+        if buf is None:
+            # zeros: the block trailer's `bad` mark must not match a pack epoch by accident (include/imdbn_engine.h)
+            buf = self._ws[key] = torch.zeros(world, self.compact_bytes(W.shape[0], W.shape[1], B, binary), dtype=torch.uint8, device=W.device)
+        return buf
+
+    def pack_factors(self, rbm, block: torch.Tensor, B, binary: bool) -> torch.Tensor:
+        """This rank's factor block -> its compact wire form (a reusable buffer)."""
+        W = rbm.W.data
+        out = self._wire_buffer("wire1", rbm, B, 1, binary)[0]
+        N.check(self._lib.imdbn_rbm_pack_factors(int(W.shape[0]), int(W.shape[1]), int(B), int(bool(binary)), _ptr(block), _ptr(out),
+                                                  self._stream(W.device)), "imdbn_rbm_pack_factors")
+        return out
+
+    def compact_gather_buffer(self, rbm, B, world, binary: bool) -> torch.Tensor:
+        return self._wire_buffer("wireN", rbm, B, world, binary)
+
+    def unpack_factors(self, rbm, compact: torch.Tensor, B, binary: bool) -> torch.Tensor:
+        """[world, compact bytes] gathered wire blocks -> [world, block bytes] full blocks for apply_factors."""
+        W = rbm.W.data
+        world = int(compact.size(0))
+        full = self.gather_buffer(rbm, B, world)
+        assert compact.dtype == torch.uint8 and compact.dim() == 2 and compact.is_contiguous()
+        N.check(self._lib.imdbn_rbm_unpack_factors(int(W.shape[0]), int(W.shape[1]), int(B), int(bool(binary)), _ptr(compact),
+                                                    int(compact.stride(0)), world, _ptr(full), int(full.stride(0)),
+                                                    self._stream(W.device)), "imdbn_rbm_unpack_factors")
+        return full
+
     def apply_factors(self, rbm, gathered, rows_per_rank, global_B, lr, mom):
         d = self._desc(rbm, True)
         dev = gathered.device

@@ -74,6 +74,9 @@ SIGNATURES = {
     "imdbn_rbm_cd_step": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
     "imdbn_packed_delta_floats": (_SZ, [_INT, _INT]),
     "imdbn_rbm_prefetch_ok": (_INT, [C.POINTER(RbmDesc), _INT]),
+    "imdbn_factor_compact_bytes": (_INT, [_INT, _INT, _INT, _INT, C.POINTER(_SZ)]),
+    "imdbn_rbm_pack_factors": (_INT, [_INT, _INT, _INT, _INT, _P, _P, _P]),
+    "imdbn_rbm_unpack_factors": (_INT, [_INT, _INT, _INT, _INT, _P, _SZ, _INT, _P, _SZ, _P]),
     "imdbn_rbm_cd_stats": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
     "imdbn_rbm_apply_delta": (_INT, [C.POINTER(RbmDesc), _P, _INT, C.POINTER(CdOpts), _P, _P]),
     "imdbn_factor_block": (_INT, [_INT, _INT, _INT, C.POINTER(_SZ), C.POINTER(_SZ)]),

@@ -177,7 +177,14 @@ class RBM(nn.Module):
             if dp.mode() == "factors" and hasattr(eng, "factor_mode_ok") and eng.factor_mode_ok(self, B):
                 # exchange the factors (~7 MB per rank at 10000 x 1500) instead of the fp32 statistics (60 MB)
                 block = eng.cd_factors(self, x, CD, rng)
-                gathered = dp.all_gather_blocks(eng.gather_buffer(self, B, dp.world_size()), block)
+                if hasattr(eng, "pack_factors"):
+                    # wire form: the visible planes as bits (the sample always, the data when declared binary)
+                    binary = dp.binary_data()
+                    wire = eng.pack_factors(self, block, B, binary)
+                    wires = dp.all_gather_blocks(eng.compact_gather_buffer(self, B, dp.world_size(), binary), wire)
+                    gathered = eng.unpack_factors(self, wires, B, binary)
+                else:
+                    gathered = dp.all_gather_blocks(eng.gather_buffer(self, B, dp.world_size()), block)
                 return eng.apply_factors(self, gathered, B, B * dp.world_size(), lr, mom)
             buf = eng.packed_buffer(self) if hasattr(eng, "packed_buffer") else None
             packed = eng.cd_stats(self, x, CD, rng, out=buf)

@@ -574,3 +574,31 @@ def test_next_batch_prefetch_is_bit_identical_and_guards_against_stale_data(V, H
             assert len(_native._pf) == 1
             _native.set_option("no_prefetch", 0)                      # clears the engine's prefetch state
             assert len(_native._pf) == 0
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_factor_wire_form_round_trips_and_poisons_on_a_false_promise(binary, _native):
+    """Wire form of the factor block (bit-packed visible planes): pack -> (all-gather) -> unpack gives apply_factors
+    the same bits as the full blocks; a data plane declared binary that is not turns the update into NaN."""
+    from imdbn import engine as E
+    V, H, B, R = 2048, 512, 40, 3
+    g = np.random.default_rng(12)
+    Xs = [P.T((g.random((B, V), dtype=F32) > 0.7).astype(F32), DEV) for _ in range(R)]
+    r0, _, _ = _mk(V, H, None, seed=2)
+    blocks = [_native.cd_factors(r0, Xs[k], 1, E.PhiloxRng(seed=9, row0=k * B)).clone() for k in range(R)]
+    wires = torch.stack([_native.pack_factors(r0, b, B, binary).clone() for b in blocks])
+    assert wires.size(1) == _native.compact_bytes(V, H, B, binary) < blocks[0].numel() * (0.5 if binary else 0.9)
+    ra, _, _ = _mk(V, H, None, seed=2)
+    rb, _, _ = _mk(V, H, None, seed=2)
+    la = _native.apply_factors(ra, torch.stack(blocks), B, B * R, 0.1, 0.5)
+    lb = _native.apply_factors(rb, _native.unpack_factors(rb, wires, B, binary), B, B * R, 0.1, 0.5)
+    assert float(la) == float(lb)
+    for k in P.KEYS:
+        ta, tb = getattr(ra, k), getattr(rb, k)
+        assert torch.equal(ta.data if hasattr(ta, "data") else ta, tb.data if hasattr(tb, "data") else tb), k
+    if binary:
+        bad = _native.cd_factors(r0, P.T(g.random((B, V), dtype=F32), DEV), 1, E.PhiloxRng(seed=9)).clone()
+        w = torch.stack([_native.pack_factors(r0, bad, B, True).clone()])
+        rc, _, _ = _mk(V, H, None, seed=2)
+        _native.apply_factors(rc, _native.unpack_factors(rc, w, B, True), B, B, 0.1, 0.5)
+        assert torch.isnan(rc.hid_bias.data).any()

@@ -207,7 +207,13 @@ int    imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, in
 int    imdbn_factor_compact_bytes(int V, int H, int B, int binary_data, size_t* bytes);
 int    imdbn_rbm_pack_factors(int V, int H, int B, int binary_data, const void* block, void* compact, imdbn_stream_t stream);
 int    imdbn_rbm_unpack_factors(int V, int H, int B, int binary_data, const void* compact, size_t compact_stride, int n_ranks,
-                                void* gathered, size_t full_stride, imdbn_stream_t stream);
+                                void* gathered, size_t full_stride, int planes_only, imdbn_stream_t stream);
+/* apply_factors reading the blocks' head (everything before the visible planes: verbatim in the wire form) straight
+ * from the gathered wire blocks and the visible planes from the buffer unpack(planes_only = 1) expanded them into
+ * (full-block layout, planes_stride apart): no copy of the 1.9 MB head per rank. */
+int    imdbn_rbm_apply_factors_wire(const imdbn_rbm_desc* d, const void* wire, size_t wire_stride, const void* planes,
+                                    size_t planes_stride, int n_ranks, int rows_per_rank, int global_B,
+                                    const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream);
 
 /* ---- K4: conditional chains (rbm.py:240-400) -------------------------------------------- */
 /* v0 = v_known*mask + (1-mask)*U (init_uniform=1) or v_known (0); then n_steps steps; out_v[B][V].

@@ -1005,7 +1005,7 @@ int imdbn_rbm_pack_factors(int V, int H, int B, int binary_data, const void* blo
 }
 
 int imdbn_rbm_unpack_factors(int V, int H, int B, int binary_data, const void* compact, size_t compact_stride, int n_ranks,
-                             void* gathered, size_t full_stride, imdbn_stream_t stream) {
+                             void* gathered, size_t full_stride, int planes_only, imdbn_stream_t stream) {
     if (V <= 0 || H <= 0 || B <= 0 || !compact || !gathered || n_ranks < 1 || (((uintptr_t)compact | (uintptr_t)gathered | compact_stride | full_stride) & 15))
         return fail(IMDBN_E_INVALID, "unpack_factors: bad argument (blocks and strides must be 16-B aligned)");
     size_t cb = 0;
@@ -1014,7 +1014,8 @@ int imdbn_rbm_unpack_factors(int V, int H, int B, int binary_data, const void* c
     CHK(imdbn_factor_block(V, H, B, &off, &fbytes));
     if (compact_stride < cb || full_stride < fbytes) return fail(IMDBN_E_INVALID, "unpack_factors: strides smaller than the blocks");
     w.src = (const char*)compact; w.dst = (char*)gathered; w.src_stride = compact_stride; w.dst_stride = full_stride; w.n_ranks = n_ranks;
-    hipLaunchKernelGGL(factor_unpack, dim3(std::min(512, cdiv((int)(w.head_bytes / 16), 256)), n_ranks), dim3(256), 0, S(stream), w);
+    w.planes_only = planes_only ? 1 : 0;
+    hipLaunchKernelGGL(factor_unpack, dim3(std::min(512, cdiv((int)((planes_only ? (size_t)V * w.Bp / 8 * 16 : w.head_bytes) / 16), 256)), n_ranks), dim3(256), 0, S(stream), w);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1030,20 +1031,24 @@ int imdbn_rbm_cd_factors(const imdbn_rbm_desc* d, const float* data, int64_t ldd
     return c.rng.finish();
 }
 
-int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n_ranks, size_t rank_stride, int rows_per_rank,
-                            int global_B, const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream) {
+// The update from n_ranks factor blocks.  `head` / `planes`: where the blocks' head (exactness map, hidden planes, column-sum
+// and error partials) and visible planes are read -- the same buffer and stride for full gathered blocks, or the gathered
+// WIRE blocks (whose head is verbatim) plus the buffer imdbn_rbm_unpack_factors(planes_only) expanded the planes into.
+static int apply_factors_impl(const imdbn_rbm_desc* d, const void* head, size_t head_stride, const void* planes, size_t planes_stride,
+                              int n_ranks, int rows_per_rank, int global_B, const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream) {
     CHK(check_desc(d, true));
-    if (!gathered || !o || n_ranks < 1 || global_B <= 0) return fail(IMDBN_E_INVALID, "apply_factors: bad argument");
+    if (!head || !planes || !o || n_ranks < 1 || global_B <= 0) return fail(IMDBN_E_INVALID, "apply_factors: bad argument");
     if (!factor_mode_ok(d, rows_per_rank, true)) return fail(IMDBN_E_UNSUPPORTED, "apply_factors: needs <= 64 rows per rank, 16-B aligned weight rows, no softmax groups");
     Ctx c(d, nullptr, S(stream));
-    const Layout L0 = make_layout(d->V, d->H, rows_per_rank, nullptr);          // offsets of the factor block
-    if (rank_stride < L0.fb_bytes || (rank_stride & 255) || (((uintptr_t)gathered) & 255))
-        return fail(IMDBN_E_INVALID, "apply_factors: the gathered blocks must be 256-B aligned and at least %zu bytes apart", L0.fb_bytes);
-    // carve the layout over a base chosen so that its factor block IS rank 0's gathered block (nothing outside the
-    // block is touched here)
-    c.L = make_layout(d->V, d->H, rows_per_rank, const_cast<char*>((const char*)gathered) - L0.fb_off);
+    char* fake = reinterpret_cast<char*>((uintptr_t)1 << 30);                   // only offsets inside the factor block are used
+    c.L = make_layout(d->V, d->H, rows_per_rank, fake);
     const Layout& L = c.L;
-    auto at = [&](const void* layout_ptr, int rk) { return (const char*)layout_ptr + (size_t)rk * rank_stride; };
+    const char* fb = fake + L.fb_off;
+    if (((head_stride | planes_stride) & 255) || ((((uintptr_t)head) | ((uintptr_t)planes)) & 255) || planes_stride < L.fb_bytes ||
+        head_stride < (size_t)((const char*)L.vis_tr[0] - fb))
+        return fail(IMDBN_E_INVALID, "apply_factors: the gathered blocks must be 256-B aligned and at least %zu bytes apart", L.fb_bytes);
+    auto at_h = [&](const void* layout_ptr, int rk) { return (const char*)head + ((const char*)layout_ptr - fb) + (size_t)rk * head_stride; };
+    auto at_v = [&](const void* layout_ptr, int rk) { return (const char*)planes + ((const char*)layout_ptr - fb) + (size_t)rk * planes_stride; };
     AssocPlanesArgs f;
     memset(&f, 0, sizeof(f));
     f.W = d->W; f.Wm = d->W_m; f.ldw = d->ldw; f.V = L.V; f.H = L.H;
@@ -1053,25 +1058,24 @@ int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n
     BiasArgs b;
     memset(&b, 0, sizeof(b));
     b.hid_bias = d->hid_bias; b.hb_m = d->hb_m; b.H = L.H; b.vis_bias = d->vis_bias; b.vb_m = d->vb_m; b.V = L.V;
-    b.hpos = (const float*)at(L.cs_hpos, 0); b.hneg = (const float*)at(L.cs_hneg, 0);
-    b.vpos = (const float*)at(L.cs_vpos, 0); b.vneg = (const float*)at(L.cs_vneg, 0);
+    b.hpos = (const float*)at_h(L.cs_hpos, 0); b.hneg = (const float*)at_h(L.cs_hneg, 0);
+    b.vpos = (const float*)at_h(L.cs_vpos, 0); b.vneg = (const float*)at_h(L.cs_vneg, 0);
     b.P = L.P; b.lr = o->lr; b.mom = o->momentum; b.n = (float)global_B;
     b.sparsity = o->sparsity ? 1 : 0; b.target = o->sparsity_target;
-    b.loss_part = (const float*)at(L.loss_part, 0); b.n_loss = n_loss_used(c, false);
+    b.loss_part = (const float*)at_h(L.loss_part, 0); b.n_loss = n_loss_used(c, false);
     b.loss_den = (float)global_B * (float)L.V; b.loss_out = loss_out;
-    b.R = n_ranks; b.rs = (int64_t)(rank_stride / 4);
+    b.R = n_ranks; b.rs = (int64_t)(head_stride / 4);
     BiasArgs bz;
     memset(&bz, 0, sizeof(bz));
     const int nh = cdiv(L.H, 128), nv = cdiv(L.V, 128);
     const int tpb = std::max(1, cdiv(nh * nv, std::max(cu_count(), 1)));
     const int brows = nh >= 2 ? 1 : 2;
     // all rank blocks inside one launch (the weights move once) when the visible operands need <= 4 plane slices
-    // (measured at 10000 x 1500: 2 / 4 / 8 blocks 85 / 119 / 189 us here, 83 / 140 / 251 us as one launch per block)
     if (n_ranks >= g_min_rank_loop && !g_no_rank_loop && f.vneg_terms == 1) {
-        f.vpos = (const bf16_t*)at(L.vis_tr[0], 0); f.vpos_flag = (const int*)at(L.flags, 0);
-        f.hpos = (const bf16_t*)at(L.hid_tr[0], 0);
-        f.vneg = (const bf16_t*)at(L.vis_tr[1], 0); f.hneg = (const bf16_t*)at(L.hid_tr[1], 0);
-        RankLoopArgs rl{n_ranks, (int64_t)(rank_stride / 2)};
+        f.vpos = (const bf16_t*)at_v(L.vis_tr[0], 0); f.vpos_flag = (const int*)at_h(L.flags, 0);
+        f.hpos = (const bf16_t*)at_h(L.hid_tr[0], 0);
+        f.vneg = (const bf16_t*)at_v(L.vis_tr[1], 0); f.hneg = (const bf16_t*)at_h(L.hid_tr[1], 0);
+        RankLoopArgs rl{n_ranks, (int64_t)(head_stride / 2), (int64_t)(planes_stride / 2)};
         dim3 g(nh, cdiv(nv, tpb) + brows);
         const bool acc = tpb <= 4 && !g_no_rank_acc;       // rank loop outside the tile loop: hidden planes staged once per rank
         if (c.rt == 3) { if (acc) hipLaunchKernelGGL((assoc_update_planes_ranks<3, true>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows);
@@ -1082,9 +1086,9 @@ int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n
         return 0;
     }
     for (int rk = 0; rk < n_ranks; ++rk) {
-        f.vpos = (const bf16_t*)at(L.vis_tr[0], rk); f.vpos_flag = (const int*)at(L.flags, rk);
-        f.hpos = (const bf16_t*)at(L.hid_tr[0], rk);
-        f.vneg = (const bf16_t*)at(L.vis_tr[1], rk); f.hneg = (const bf16_t*)at(L.hid_tr[1], rk);
+        f.vpos = (const bf16_t*)at_v(L.vis_tr[0], rk); f.vpos_flag = (const int*)at_h(L.flags, rk);
+        f.hpos = (const bf16_t*)at_h(L.hid_tr[0], rk);
+        f.vneg = (const bf16_t*)at_v(L.vis_tr[1], rk); f.hneg = (const bf16_t*)at_h(L.hid_tr[1], rk);
         const int pass = n_ranks == 1 ? 0 : (rk == 0 ? 1 : (rk == n_ranks - 1 ? 3 : 2));
         const int br = (rk == n_ranks - 1) ? brows : 0;
         const BiasArgs& bb = br ? b : bz;
@@ -1098,6 +1102,16 @@ int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n_ranks, size_t rank_stride, int rows_per_rank,
+                            int global_B, const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream) {
+    return apply_factors_impl(d, gathered, rank_stride, gathered, rank_stride, n_ranks, rows_per_rank, global_B, o, loss_out, stream);
+}
+
+int imdbn_rbm_apply_factors_wire(const imdbn_rbm_desc* d, const void* wire, size_t wire_stride, const void* planes, size_t planes_stride,
+                                 int n_ranks, int rows_per_rank, int global_B, const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream) {
+    return apply_factors_impl(d, wire, wire_stride, planes, planes_stride, n_ranks, rows_per_rank, global_B, o, loss_out, stream);
 }
 
 int imdbn_rbm_apply_delta(const imdbn_rbm_desc* d, const float* packed, int global_B, const imdbn_cd_opts* o,

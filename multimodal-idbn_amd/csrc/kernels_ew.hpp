@@ -694,6 +694,7 @@ struct FactorWireArgs {
     size_t f_vpos, f_vneg, f_cs_hpos;      // offsets inside the full block: vis_tr[0] (3 planes), vis_tr[1] (first plane), cs_hpos
     size_t c_vneg, c_vpos, c_bad;          // offsets inside the compact block
     int V, Bp, binary;
+    int planes_only;                       // unpack: leave the head where it is (the update reads it from the wire blocks)
     int epoch;                             // pack: a value that differs from call to call (no memset of the `bad` word needed)
 };
 
@@ -747,10 +748,15 @@ __global__ __launch_bounds__(256) void factor_unpack(const FactorWireArgs a) {
     char* dst = a.dst + (size_t)blockIdx.y * a.dst_stride;
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthr = (int64_t)gridDim.x * 256;
     const bool bad = reinterpret_cast<const int*>(src + a.c_bad)[0] == reinterpret_cast<const int*>(src + a.c_bad)[1];
-    for (int64_t i = tid; i < (int64_t)(a.head_bytes / 16); i += nthr) {
-        uint4 x = reinterpret_cast<const uint4*>(src)[i];
-        if (bad && i == (int64_t)(a.f_cs_hpos / 16)) x.x = 0x7FC00000u;       // NaN into the first hidden column-sum partial
-        reinterpret_cast<uint4*>(dst)[i] = x;
+    if (a.planes_only) {
+        // the head stays in the wire block (this process's own gather buffer): poison it there
+        if (bad && tid == 0) *reinterpret_cast<uint32_t*>(const_cast<char*>(src) + a.f_cs_hpos) = 0x7FC00000u;
+    } else {
+        for (int64_t i = tid; i < (int64_t)(a.head_bytes / 16); i += nthr) {
+            uint4 x = reinterpret_cast<const uint4*>(src)[i];
+            if (bad && i == (int64_t)(a.f_cs_hpos / 16)) x.x = 0x7FC00000u;   // NaN into the first hidden column-sum partial
+            reinterpret_cast<uint4*>(dst)[i] = x;
+        }
     }
     const int64_t nb = (int64_t)a.V * a.Bp / 8;
     for (int64_t i = tid; i < nb; i += nthr)

@@ -957,7 +957,9 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
 // read-modify-write: the weights move once whatever R is.  Per (tile, rank) the block restages that rank's hidden
 // planes (96 KB from L2, LDS-DMA) and its visible slices; two block barriers per rank (the hidden planes are shared
 // by the four waves), so the barrier-free schedule of the single-block kernel does not apply here.
-struct RankLoopArgs { int n_ranks; int64_t stride; };      // stride: elements (bf16) between the rank blocks' operands; flags: stride/2 ints
+// strides in bf16 elements between the rank blocks: _h for the hidden planes and the exactness map (ints: stride_h / 2),
+// _v for the visible planes (they differ when the head of the blocks is read from the gathered wire blocks)
+struct RankLoopArgs { int n_ranks; int64_t stride_h, stride_v; };
 
 template <int HT>
 __device__ __forceinline__ void k3_body_ranks(const AssocPlanesArgs& a, const RankLoopArgs& rl, char* smem, int bx, int by,
@@ -988,7 +990,7 @@ __device__ __forceinline__ void k3_body_ranks(const AssocPlanesArgs& a, const Ra
         }
     };
     auto dma_rank = [&](int rk, int v0w) {                          // hidden planes + this wave's visible slices of rank rk
-        const int64_t ro = (int64_t)rk * rl.stride;
+        const int64_t ro = (int64_t)rk * rl.stride_h, rov = (int64_t)rk * rl.stride_v;
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -1003,7 +1005,7 @@ __device__ __forceinline__ void k3_body_ranks(const AssocPlanesArgs& a, const Ra
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int pl = min(p, P - 1);
-            const bf16_t* src = (pl < nap ? a.vpos + pl * a.vts : a.vneg + (pl - nap) * a.vts) + ro;
+            const bf16_t* src = (pl < nap ? a.vpos + pl * a.vts : a.vneg + (pl - nap) * a.vts) + rov;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = l + 64 * q, row = i >> 3, c = (i & 7) ^ ((row >> 1) & 7);
@@ -1094,7 +1096,7 @@ __device__ __forceinline__ void k3_body_ranks_acc(const AssocPlanesArgs& a, cons
     const bool dbl = P <= 2;                                        // two slot pairs: stage tile t+1 under the MFMAs of tile t
 
     auto dma_hidden = [&](int rk) {                                  // 2 x HT planes of rank rk, all four waves: 8 HT ops per wave
-        const int64_t ro = (int64_t)rk * rl.stride;
+        const int64_t ro = (int64_t)rk * rl.stride_h;
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -1110,7 +1112,7 @@ __device__ __forceinline__ void k3_body_ranks_acc(const AssocPlanesArgs& a, cons
     // this wave's visible slices of (rank rk, rows v0w ..): planes 0..1 into slots base, base+1 (dbl) or planes 0..3 into slots 0..3;
     // always 8 (dbl) or 16 ops
     auto dma_slices = [&](int rk, int v0w, int base) {
-        const int64_t ro = (int64_t)rk * rl.stride;
+        const int64_t ro = (int64_t)rk * rl.stride_v;
         const int np = dbl ? 2 : 4;
         for (int p = 0; p < np; ++p) {
             const int pl = min(p, P - 1);
@@ -1225,7 +1227,7 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes_ranks(const AssocP
     if (nap == 0) {                                                  // any rank with inexact data in these tiles -> three terms for all
         nap = 1;
         for (int rk = 0; rk < rl.n_ranks; ++rk)
-            nap = max(nap, operand_terms(a.vpos_flag + rk * (rl.stride / 2), ncbv, a.Bp / 8, (tile0 * 128) / 64, (tile0 + tiles_per_block) * 2, 0));
+            nap = max(nap, operand_terms(a.vpos_flag + rk * (rl.stride_h / 2), ncbv, a.Bp / 8, (tile0 * 128) / 64, (tile0 + tiles_per_block) * 2, 0));
     }
     if constexpr (ACC) k3_body_ranks_acc<HT>(a, rl, smem, bx, by, tiles_per_block, nap, a.vneg_terms);
     else               k3_body_ranks<HT>(a, rl, smem, bx, by, tiles_per_block, nap, a.vneg_terms);

@@ -371,16 +371,28 @@ class HipEngine:
     def compact_gather_buffer(self, rbm, B, world, binary: bool) -> torch.Tensor:
         return self._wire_buffer("wireN", rbm, B, world, binary)
 
-    def unpack_factors(self, rbm, compact: torch.Tensor, B, binary: bool) -> torch.Tensor:
-        """[world, compact bytes] gathered wire blocks -> [world, block bytes] full blocks for apply_factors."""
+    def unpack_factors(self, rbm, compact: torch.Tensor, B, binary: bool, planes_only: bool = False) -> torch.Tensor:
+        """[world, compact bytes] gathered wire blocks -> [world, block bytes] full blocks for apply_factors
+        (``planes_only``: just the visible planes, for apply_factors_wire)."""
         W = rbm.W.data
         world = int(compact.size(0))
         full = self.gather_buffer(rbm, B, world)
         assert compact.dtype == torch.uint8 and compact.dim() == 2 and compact.is_contiguous()
         N.check(self._lib.imdbn_rbm_unpack_factors(int(W.shape[0]), int(W.shape[1]), int(B), int(bool(binary)), _ptr(compact),
                                                     int(compact.stride(0)), world, _ptr(full), int(full.stride(0)),
-                                                    self._stream(W.device)), "imdbn_rbm_unpack_factors")
+                                                    int(bool(planes_only)), self._stream(W.device)), "imdbn_rbm_unpack_factors")
         return full
+
+    def apply_factors_wire(self, rbm, wires: torch.Tensor, planes: torch.Tensor, rows_per_rank, global_B, lr, mom):
+        """apply_factors with the blocks' head read from the gathered wire blocks and the visible planes from `planes`."""
+        d = self._desc(rbm, True)
+        dev = wires.device
+        o = self._opts(rbm, lr, mom, 1, sparsity=getattr(rbm, "sparsity", False))
+        loss = torch.empty(1, device=dev)
+        N.check(self._lib.imdbn_rbm_apply_factors_wire(C.byref(d), _ptr(wires), int(wires.stride(0)), _ptr(planes), int(planes.stride(0)),
+                                                        int(wires.size(0)), int(rows_per_rank), int(global_B), C.byref(o), _ptr(loss),
+                                                        self._stream(dev)), "imdbn_rbm_apply_factors_wire")
+        return loss.reshape(())
 
     def apply_factors(self, rbm, gathered, rows_per_rank, global_B, lr, mom):
         d = self._desc(rbm, True)

@@ -182,6 +182,9 @@ class RBM(nn.Module):
                     binary = dp.binary_data()
                     wire = eng.pack_factors(self, block, B, binary)
                     wires = dp.all_gather_blocks(eng.compact_gather_buffer(self, B, dp.world_size(), binary), wire)
+                    if hasattr(eng, "apply_factors_wire"):       # the head of the blocks is read from the wire blocks in place
+                        planes = eng.unpack_factors(self, wires, B, binary, planes_only=True)
+                        return eng.apply_factors_wire(self, wires, planes, B, B * dp.world_size(), lr, mom)
                     gathered = eng.unpack_factors(self, wires, B, binary)
                 else:
                     gathered = dp.all_gather_blocks(eng.gather_buffer(self, B, dp.world_size()), block)

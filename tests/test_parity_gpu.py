@@ -592,13 +592,20 @@ def test_factor_wire_form_round_trips_and_poisons_on_a_false_promise(binary, _na
     rb, _, _ = _mk(V, H, None, seed=2)
     la = _native.apply_factors(ra, torch.stack(blocks), B, B * R, 0.1, 0.5)
     lb = _native.apply_factors(rb, _native.unpack_factors(rb, wires, B, binary), B, B * R, 0.1, 0.5)
-    assert float(la) == float(lb)
+    rw, _, _ = _mk(V, H, None, seed=2)             # head read from the wire blocks in place, planes unpacked
+    w2 = wires.clone()
+    lw = _native.apply_factors_wire(rw, w2, _native.unpack_factors(rw, w2, B, binary, planes_only=True), B, B * R, 0.1, 0.5)
+    assert float(la) == float(lb) == float(lw)
     for k in P.KEYS:
-        ta, tb = getattr(ra, k), getattr(rb, k)
-        assert torch.equal(ta.data if hasattr(ta, "data") else ta, tb.data if hasattr(tb, "data") else tb), k
+        ta, tb, tw = getattr(ra, k), getattr(rb, k), getattr(rw, k)
+        d = lambda t: t.data if hasattr(t, "data") else t
+        assert torch.equal(d(ta), d(tb)) and torch.equal(d(ta), d(tw)), k
     if binary:
         bad = _native.cd_factors(r0, P.T(g.random((B, V), dtype=F32), DEV), 1, E.PhiloxRng(seed=9)).clone()
         w = torch.stack([_native.pack_factors(r0, bad, B, True).clone()])
         rc, _, _ = _mk(V, H, None, seed=2)
         _native.apply_factors(rc, _native.unpack_factors(rc, w, B, True), B, B, 0.1, 0.5)
         assert torch.isnan(rc.hid_bias.data).any()
+        rd, _, _ = _mk(V, H, None, seed=2)
+        _native.apply_factors_wire(rd, w, _native.unpack_factors(rd, w, B, True, planes_only=True), B, B, 0.1, 0.5)
+        assert torch.isnan(rd.hid_bias.data).any()

@@ -198,6 +198,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(loss).item(), "loss is not finite"
+    replicas_identical = None
+    if world > 1:      # after the timed region: every rank applied the same update, so the replicas must agree bit for bit
+        chk = torch.stack([rbm.W.data.double().sum(), rbm.W.data.double().abs().sum(), rbm.hid_bias.data.double().sum()])
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        replicas_identical = all(torch.equal(allc[0], c) for c in allc)
 
     if rank == 0:
         # unit = one batch-64 CD-1 update; every rank processes one per step (the step updates the shared weights
@@ -215,7 +221,7 @@ def main():
                        "dp_exchange": ((args.dp_mode + ("" if args.dp_mode != "factors" else (" (wire form: sample as bits)" if args.dp_full_planes else " (wire form: data and sample as bits)")))
                                        if (world > 1 or args.force_dp) else None),
                        "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
-                       "final_loss": float(loss)},
+                       "final_loss": float(loss), "replicas_identical": replicas_identical},
             "global_steps_per_s": args.steps / dt,
             "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
             "host_enqueue_us_p50_max": _p50_max(t0, stamps),

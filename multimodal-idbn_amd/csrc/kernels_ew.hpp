@@ -397,10 +397,26 @@ __device__ __forceinline__ void finish_groups_body(const FinishArgs& a, int loss
     __syncthreads();
     if (tid < 64) {
         const int b = min(rb * 64 + tid, a.B - 1);
+        // 8 LDS values at a time ahead of each dependent chain (a round trip per element otherwise); same summation order
         float mx = -INFINITY;
-        for (int j = 0; j < wd; ++j) mx = fmaxf(mx, sL[tid][j]);
+        int j0 = 0;
+        for (; j0 + 8 <= wd; j0 += 8) {
+            float e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = sL[tid][j0 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mx = fmaxf(mx, e[k]);
+        }
+        for (; j0 < wd; ++j0) mx = fmaxf(mx, sL[tid][j0]);
         float sum = 0.f;
-        for (int j = 0; j < wd; ++j) sum += expf(sL[tid][j] - mx);
+        for (j0 = 0; j0 + 8 <= wd; j0 += 8) {
+            float e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = expf(sL[tid][j0 + k] - mx);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += e[k];
+        }
+        for (; j0 < wd; ++j0) sum += expf(sL[tid][j0] - mx);
         int idx = -1;
         if (a.vmode != 0) {
             if (a.cat_tape) idx = a.cat_tape[(int64_t)g * a.B + b];

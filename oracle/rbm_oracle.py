@@ -24,6 +24,22 @@ import numpy as np
 
 F32 = np.float32
 
+# Smallest |p - u| seen at a Bernoulli draw since the last reset: an accelerator result that differs from this
+# restatement by ONE flipped sample is legitimate when that margin is at rounding level (tools/stress_parity.py, fixtures).
+BERNOULLI_MARGIN = {"min": float("inf")}
+
+
+def reset_margin():
+    BERNOULLI_MARGIN["min"] = float("inf")
+
+
+def _bern(p, u):
+    """1[p > u] as float32, tracking the smallest margin."""
+    if p.size:
+        BERNOULLI_MARGIN["min"] = min(BERNOULLI_MARGIN["min"], float(np.abs(p - u).min()))
+    return (p > u).astype(F32)
+
+
 
 def _f(x) -> np.float32:
     return np.float32(x)
@@ -132,7 +148,7 @@ def visible_probs(st: RBMState, h: np.ndarray, T: float = 1.0) -> np.ndarray:
 def sample_visible(st: RBMState, v_prob: np.ndarray, rng) -> np.ndarray:
     """rbm.py:125-135: Bernoulli over ALL columns, then one categorical per softmax group."""
     u = rng.uniform(v_prob.shape)
-    v = (v_prob > u).astype(F32)
+    v = _bern(v_prob, u)
     for s, e in st.softmax_groups:
         probs = np.clip(v_prob[:, s:e], F32(1e-8), F32(1.0)).astype(F32)
         idx = rng.categorical(probs)
@@ -156,7 +172,7 @@ def backward_sample(st: RBMState, h, rng):
 def gibbs_step(st: RBMState, v, rng, sample_h=True, sample_v=True):
     """rbm.py:174-178."""
     h_prob = forward(st, v)
-    h = (h_prob > rng.uniform(h_prob.shape)).astype(F32) if sample_h else h_prob
+    h = _bern(h_prob, rng.uniform(h_prob.shape)) if sample_h else h_prob
     v_prob = visible_probs(st, h)
     v_next = sample_visible(st, v_prob, rng) if sample_v else v_prob
     return v_next, v_prob, h, h_prob
@@ -180,13 +196,13 @@ def cd_statistics(st: RBMState, data: np.ndarray, CD: int, rng):
     data = np.asarray(data, F32)
     pos_h = forward(st, data)                                  # :199
     pos_assoc = (data.T @ pos_h).astype(F32)                   # :200
-    h = (pos_h > rng.uniform(pos_h.shape)).astype(F32)         # :203
+    h = _bern(pos_h, rng.uniform(pos_h.shape))         # :203
     v = v_prob = h_prob = None
     for _ in range(int(CD)):                                   # :204
         v_prob = visible_probs(st, h)                          # :205
         v = sample_visible(st, v_prob, rng)                    # :206
         h_prob = forward(st, v)                                # :207
-        h = (h_prob > rng.uniform(h_prob.shape)).astype(F32)   # :208 (last draw discarded)
+        h = _bern(h_prob, rng.uniform(h_prob.shape))   # :208 (last draw discarded)
     neg_assoc = (v.T @ h_prob).astype(F32)                     # :209
     return dict(
         pos_assoc=pos_assoc, neg_assoc=neg_assoc,
@@ -305,7 +321,7 @@ def conditional_gibbs(st: RBMState, v_known, known_mask, rng, n_steps=30, sample
     v = v_known * km + (F32(1) - km) * rng.uniform(v_known.shape)              # :392
     for _ in range(int(n_steps)):
         h_prob = forward(st, v)                                               # :394
-        h = (h_prob > rng.uniform(h_prob.shape)).astype(F32) if sample_h else h_prob
+        h = _bern(h_prob, rng.uniform(h_prob.shape)) if sample_h else h_prob
         v_prob = visible_probs(st, h)                                         # :396
         v = (v_prob * (F32(1) - km) + v_known * km).astype(F32)               # :397
         if sample_v:
@@ -326,7 +342,7 @@ def conditional_gibbs_annealed(st: RBMState, v_known, known_mask, rng, n_steps=4
         if (n - t) <= 3:
             Tt = min(0.9, Tt)                                                 # :278-279
         h_prob = forward(st, v, T=Tt)
-        h = (h_prob > rng.uniform(h_prob.shape)).astype(F32) if t < hot else h_prob   # :282
+        h = _bern(h_prob, rng.uniform(h_prob.shape)) if t < hot else h_prob   # :282
         v_prob = visible_probs(st, h, T=Tt)
         if (t < hot) and (sample_v_every > 0) and (t % sample_v_every == 0):
             v_new = sample_visible(st, v_prob, rng)                           # :286
@@ -358,7 +374,7 @@ def clamped_statistics(st: RBMState, v_known, known_mask, rng, CD=1, cond_init_s
     v_neg = v_plus.copy()
     for _ in range(int(CD)):                                                  # :460-469
         h_prob = forward(st, v_neg)
-        h = (h_prob > rng.uniform(h_prob.shape)).astype(F32) if sample_h else h_prob
+        h = _bern(h_prob, rng.uniform(h_prob.shape)) if sample_h else h_prob
         v_prob = visible_probs(st, h)
         if reclamp_negative:
             v_neg = (v_prob * (F32(1) - km) + v_known * km).astype(F32)

@@ -366,7 +366,10 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         // K2: fused GEMM + epilogue (no split-K slabs)
         if (f.n_groups > 0 && !f.logits_only && !f.out_prob) f.out_prob = L.f_vp, f.ld_prob = L.V;
         if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
-        dim3 grid(cdiv(L.V, L.down_tr), 1, mb);
+        // tiles cover [0, Vpad): the K16-blocked operand form must have its padding columns [V, Vpad) written (zeros) -- the
+        // next K1 multiplies them with clamped (non-zero) weight rows.  Tiles of 20 / 24 / 28 rows (chosen for V in
+        // (4096, 7168]) do not end on a multiple of 16 by themselves; found by tools/stress_parity.py.
+        dim3 grid(cdiv(L.Vpad, L.down_tr), 1, mb);
         f.dbg = g_dbg;
         // sampled hidden states left by `finish` in bit-packed form: 16x less activation traffic per block
         const uint32_t* abits = (c.hid_bits_ok && in.rm == L.hid_rm && in.terms == 1 && !g_no_bits) ? L.hid_bits : nullptr;
@@ -420,7 +423,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
 }
 int n_loss_used(const Ctx& c, bool up) {
     if (up) return cdiv(c.L.H, 64) * c.L.P;
-    return (cdiv(c.L.V, c.L.down_tr) + c.d->n_groups) * (c.L.Bp / 64);    // fused K2: one partial per block (+ per group block)
+    return (cdiv(c.L.Vpad, c.L.down_tr) + c.d->n_groups) * (c.L.Bp / 64);    // fused K2: one partial per block (+ per group block)
 }
 
 // caller fp32 tensor -> operand forms in the workspace

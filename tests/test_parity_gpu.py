@@ -609,3 +609,38 @@ def test_factor_wire_form_round_trips_and_poisons_on_a_false_promise(binary, _na
         rd, _, _ = _mk(V, H, None, seed=2)
         _native.apply_factors_wire(rd, w, _native.unpack_factors(rd, w, B, True, planes_only=True), B, B, 0.1, 0.5)
         assert torch.isnan(rd.hid_bias.data).any()
+
+
+@pytest.mark.parametrize("V,H,B,rows", [(545, 380, 127, 24), (20, 468, 95, 24), (982, 24, 52, 28), (545, 64, 33, 20),
+                                        (5511, 64, 33, 0), (6301, 36, 20, 0), (4500, 40, 70, 0)])
+def test_fused_k2_row_tiles_that_do_not_end_on_16_columns(V, H, B, rows, _native):
+    """The fused K2 takes 20 / 24 / 28-row tiles for V in (4096, 7168] (rows = 0: the automatic choice; else forced):
+    its tiles must still write the operand form's padding columns [V, Vpad) -- two consecutive updates and a chain
+    (the second propagation reads what the first left) against the oracle.  Regression for a bug found by
+    tools/stress_parity.py (stale padding columns -> NaN)."""
+    from imdbn import engine as E
+    _native.set_option("down_rows", rows)
+    try:
+        r, st, g = _mk(V, H, None, seed=V + H)
+        Xs = [(g.random((B, V), dtype=F32) > 0.6).astype(F32) for _ in range(2)]
+        # poison the workspace first: stale contents must not matter
+        ws = _native._workspace(torch.device(DEV), V, H, B)
+        ws.view(torch.float32).fill_(float("nan"))
+        with E.use_rng(E.PhiloxRng(seed=3)):
+            l0 = float(r.train_epoch(P.T(Xs[0], DEV), 1, 10, CD=2))
+            l1 = float(r.train_epoch(P.T(Xs[1], DEV), 1, 10, CD=1))
+            vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+            vk[:, : V // 2] = Xs[0][:, : V // 2]; km[:, : V // 2] = 1
+            out = P.N(r.conditional_gibbs(P.T(vk, DEV), P.T(km, DEV), n_steps=2))
+        O.reset_margin()
+        s = PhiloxStream(3)
+        o0 = O.train_epoch(st, Xs[0], 1, 2, s); o1 = O.train_epoch(st, Xs[1], 1, 1, s)
+        oo = O.conditional_gibbs(st, vk, km, s, n_steps=2)
+        assert np.isfinite([l0, l1]).all() and np.isfinite(out).all()
+        if O.BERNOULLI_MARGIN["min"] > 3e-6:          # otherwise a sample was decided at rounding level: only finiteness is checked
+            assert_close(np.array([l0, l1], F32), np.array([o0, o1], F32), 1e-5, "losses")
+            for k in P.KEYS:
+                assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
+            assert_close(out, oo, 1e-4, "chain", atol=2e-6)
+    finally:
+        _native.set_option("down_rows", 0)

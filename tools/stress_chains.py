@@ -57,6 +57,7 @@ for case in range(n_cases):
         if mu is not None:
             r._mu_pull = {"mu_k": P.T(mu, DEV), "eta0": 0.2}; st.mu_pull = {"mu_k": mu, "eta0": 0.2}
         a, b = P.T(vk, DEV), P.T(km, DEV)
+        E.get_hip_engine()._workspace(torch.device(DEV), V, H, B).view(torch.float32).fill_(float("nan"))   # stale contents must not matter
         O.reset_margin()
         s = PhiloxStream(seed)
         with E.use_rng(E.PhiloxRng(seed=seed)):

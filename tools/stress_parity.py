@@ -56,6 +56,8 @@ for case in range(n_cases):
         r = RBM(V, H, 0.1, 1e-4, 0.5, **kw)
         P.set_params(r, DEV, W0, hb, vb)
         st = O.RBMState.create(W0, 0.1, 1e-4, 0.5, hid_bias=hb, vis_bias=vb, **kw)
+        # stale workspace contents must never matter: poison it (NaN) before the first call
+        E.get_hip_engine()._workspace(torch.device(DEV), V, H, B).view(torch.float32).fill_(float("nan"))
         with E.use_rng(E.PhiloxRng(seed=seed)):
             d0, d1 = P.T(Xs[0], DEV), P.T(Xs[1], DEV)
             l0 = float(r.train_epoch(d0, 2, 10, CD=cd, next_data=d1))

@@ -28,10 +28,16 @@ def rel(a, b, atol):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), atol * np.sqrt(b.size) + 1e-30))
 
+FAST = bool(os.environ.get("STRESS_FAST"))      # single-term bf16 weights (IMDBN_FAST_BF16): only finiteness can be checked
+if FAST:
+    from imdbn.engine import native as _native_mod
+    E.get_hip_engine().mode = _native_mod.FAST_BF16
 fails, ties, t0 = 0, 0, time.time()
 TIE = 3e-6        # |p - u| below this: the sample is decided by rounding (fp32 sigmoid of a 1e-6-accurate pre-activation)
 for case in range(n_cases):
     V = int(g.integers(9, 2600)); H = int(g.integers(4, 700)); B = int(g.integers(1, 230))
+    if os.environ.get("STRESS_BIG"):          # the tile-height and multi-tile regimes of the large layers
+        V = int(g.integers(4000, 9000)); H = int(g.integers(8, 1100)); B = int(g.integers(1, 140))
     if g.random() < 0.6:
         H = H // 4 * 4 + 4
     if g.random() < 0.3:
@@ -77,6 +83,9 @@ for case in range(n_cases):
                 "chain": rel(out, oo, 1e-6), "lossc": abs(lc - oc) / max(abs(oc), 1e-4)}
         for k in P.KEYS:
             errs[k] = rel(P.N(getattr(r, k)), getattr(st, k), 2e-6)
+        if FAST:
+            fin = all(np.isfinite(P.N(getattr(r, k))).all() for k in P.KEYS) and np.isfinite([l0, l1, lc]).all() and np.isfinite(out).all()
+            return ({} if fin else {"finite": 1.0}), float("inf")
         return {k: v for k, v in errs.items() if not (v < (2e-3 if k == "lossc" else 3e-4))}, O.BERNOULLI_MARGIN["min"]
 
     try:
@@ -119,7 +128,7 @@ for case in range(n_cases):
             errs = {"dp loss": abs(ld - od) / max(abs(od), 1e-6)}
             for k in P.KEYS:
                 errs["dp " + k] = rel(P.N(getattr(r2, k)), getattr(st2, k), 2e-6)
-            bad = {k: v for k, v in errs.items() if not v < 3e-4}
+            bad = {k: v for k, v in errs.items() if not (np.isfinite(v) if FAST else v < 3e-4)}
             if bad and O.BERNOULLI_MARGIN["min"] < TIE:
                 ties += 1
                 print("near-tie(dp)", tag, f"R={R} Bl={Bl} margin {O.BERNOULLI_MARGIN['min']:.1e}", {k: f"{v:.2e}" for k, v in bad.items()}, flush=True)

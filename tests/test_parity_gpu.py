@@ -644,3 +644,38 @@ def test_fused_k2_row_tiles_that_do_not_end_on_16_columns(V, H, B, rows, _native
             assert_close(out, oo, 1e-4, "chain", atol=2e-6)
     finally:
         _native.set_option("down_rows", 0)
+
+
+def test_idbn_train_lookahead_with_a_ragged_last_batch_equals_plain_loop(tmp_path):
+    """iDBN.train hands the first layer its next batch (operand forms prefetched); a smaller last batch, a second
+    layer without a hint and the epoch boundary must not change any bit."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from imdbn import engine as E
+    from imdbn.models import iDBN
+    g = np.random.default_rng(4)
+    X = torch.from_numpy((g.random((164, 4096)) > 0.8).astype(F32)).to(DEV)          # batches of 64, 64, 36
+    dl = DataLoader(TensorDataset(X, torch.zeros(len(X), 1, device=DEV)), batch_size=64)
+    params = {"LEARNING_RATE": 0.1, "WEIGHT_PENALTY": 1e-4, "INIT_MOMENTUM": 0.5, "FINAL_MOMENTUM": 0.95,
+              "LEARNING_RATE_DYNAMIC": True, "CD": 1}
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        torch.manual_seed(0); a = iDBN([4096, 256, 64], params, dl, dl, torch.device(DEV))
+        torch.manual_seed(0); b = iDBN([4096, 256, 64], params, dl, dl, torch.device(DEV))
+        for la, lb in zip(a.layers, b.layers):
+            assert torch.equal(la.W.data, lb.W.data)
+        with E.use_rng(E.PhiloxRng(seed=6)):
+            a.train(2)
+        with E.use_rng(E.PhiloxRng(seed=6)):                       # the same loop without any hint
+            for epoch in range(2):
+                for s in range(0, 164, 64):
+                    v = X[s:s + 64]
+                    for rbm in b.layers:
+                        rbm.train_epoch(v, epoch, 2, CD=1)
+                        v = rbm.forward(v)
+        for la, lb in zip(a.layers, b.layers):
+            for k in P.KEYS:
+                ta, tb = getattr(la, k), getattr(lb, k)
+                assert torch.equal(ta.data if hasattr(ta, "data") else ta, tb.data if hasattr(tb, "data") else tb), k
+    finally:
+        os.chdir(cwd)

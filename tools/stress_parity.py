@@ -138,6 +138,34 @@ for case in range(n_cases):
     except Exception as e:
         fails += 1
         print("ERROR(dp)", tag, type(e).__name__, str(e)[:200], flush=True)
+    # data-parallel all-reduce path (any shape: softmax groups, batches > 64 rows): two row shards' packed statistics,
+    # summed, applied -- against the oracle's single update of the whole batch
+    try:
+        eng = E.get_hip_engine()
+        if B >= 2:
+            r3 = RBM(V, H, 0.1, 1e-4, 0.5, **kw); P.set_params(r3, DEV, W0, hb, vb)
+            st3 = O.RBMState.create(W0, 0.1, 1e-4, 0.5, hid_bias=hb, vis_bias=vb, **kw)
+            half = B // 2
+            seed = int(g.integers(1, 1 << 30))
+            s0 = eng.cd_stats(r3, P.T(Xs[0][:half], DEV), cd, E.PhiloxRng(seed=seed, row0=0)).clone()
+            s1 = eng.cd_stats(r3, P.T(Xs[0][half:], DEV), cd, E.PhiloxRng(seed=seed, row0=half)).clone()
+            lr_, mom_ = r3._lr_mom(2)
+            la = float(eng.apply_delta(r3, s0 + s1, B, lr_, mom_))
+            O.reset_margin()
+            oa = O.train_epoch(st3, Xs[0], 2, cd, PhiloxStream(seed))
+            errs = {"ar loss": abs(la - oa) / max(abs(oa), 1e-6)}
+            for k in P.KEYS:
+                errs["ar " + k] = rel(P.N(getattr(r3, k)), getattr(st3, k), 2e-6)
+            bad = {k: v for k, v in errs.items() if not (np.isfinite(v) if FAST else v < 3e-4)}
+            if bad and O.BERNOULLI_MARGIN["min"] < TIE:
+                ties += 1
+                print("near-tie(allreduce)", tag, f"margin {O.BERNOULLI_MARGIN['min']:.1e}", {k: f"{v:.2e}" for k, v in bad.items()}, flush=True)
+            elif bad:
+                fails += 1
+                print("FAIL(allreduce)", tag, f"margin {O.BERNOULLI_MARGIN['min']:.1e}", {k: f"{v:.2e}" for k, v in bad.items()}, flush=True)
+    except Exception as e:
+        fails += 1
+        print("ERROR(allreduce)", tag, type(e).__name__, str(e)[:200], flush=True)
     if case % 20 == 19:
         print(f"... {case + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
 print(f"stress_parity: {n_cases} cases, {fails} failures, {ties} near-tie sample flips, {time.time() - t0:.0f} s")

@@ -766,8 +766,11 @@ __device__ __forceinline__ void k3_stage(char* dst, const bf16_t* src, int64_t t
 // weight prefetch.  The compiler does not count these ops; every wait it computes is then at worst too strict
 // (vmcnt retires in order), never too weak, and the "slices arrived" wait below is explicit.
 __device__ __forceinline__ void k3_dma16(const void* g, uint32_t lds_off) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory", "m0");      // wave-uniform by construction
+    // M0 (the LDS destination base) is compiler-reserved and a clobber of it is not honoured: save and restore it inside
+    // the same statement (cdna_hip_programming.md 5.7)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");      // wave-uniform by construction
 }
 
 // MFMAs of one visible plane slice (single term, this wave's 32 rows) against HT hidden planes
@@ -820,14 +823,18 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
     char* sV = smem + K3_VIS0 + w * (4 * K3_SLICE);                    // this wave's four slices
     const uint32_t sV_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)sV);
 
-    const float* Wsrc = (PASS == 2) ? a.Wm : a.W;              // middle passes do not need W: repeat the W_m address (same lines)
+    // Register loads one load_tile issues (middle passes of a multi-chunk batch do not read W).  The hand-written
+    // "planes / slices have landed" waits below are s_waitcnt vmcnt(NPF): vmcnt retires in order, the DMAs precede the
+    // prefetch, so exactly the NPF prefetch loads may stay in flight.  The count must equal the loads the compiler really
+    // emits: tests/test_isa_cpu.py checks it in the gfx950 ISA of every instantiation.
+    constexpr int NPF = MODE == 0 ? (PASS == 2 ? 16 : 32) : (PASS >= 2 ? 16 : 0);
     auto load_tile = [&](float4 (&wo)[16], float4 (&mo)[16], int v0, bool valid) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = valid ? min(v0 + 32 * w + mfma_row(reg, l), a.V - 1) : tile0 * 128;
                 const int64_t idx = (int64_t)row * a.ldw + colc;
-                wo[reg] = *reinterpret_cast<const float4*>(Wsrc + idx);
+                if constexpr (PASS != 2) wo[reg] = *reinterpret_cast<const float4*>(a.W + idx);
                 mo[reg] = *reinterpret_cast<const float4*>(a.Wm + idx);
             }
         } else {
@@ -875,8 +882,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
     __builtin_amdgcn_sched_barrier(0);
     load_tile(wA, mA, tile0 * 128, true);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(MODE == 0 ? NPF : 0) : "memory");
     __syncthreads();                                                    // the ONLY block barrier
     stamp(st, sblk, 1);
 
@@ -888,8 +894,7 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
         __builtin_amdgcn_sched_barrier(0);
         load_tile(wn, mn, v0 + 128, it + 1 < n_my);                      // next tile's weights: in flight for the whole tile
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");     // slices arrived; prefetch still in flight
-        else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(MODE == 0 ? NPF : 0) : "memory");     // slices arrived; prefetch still in flight
         f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -919,7 +924,8 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
                     const float4 d = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);   // pos_assoc - neg_assoc
                     if constexpr (MODE == 0) {
                         const int64_t idx = (int64_t)row * a.ldw + h0 + 4 * r;
-                        const float4 w0 = wc[reg];
+                        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (PASS != 2) w0 = wc[reg];                           // middle passes never load W
                         float4 m = mc[reg];
                         const float gx = POW2 ? d.x * inv_n : d.x / a.n, gy = POW2 ? d.y * inv_n : d.y / a.n;
                         const float gz = POW2 ? d.z * inv_n : d.z / a.n, gw = POW2 ? d.w * inv_n : d.w / a.n;

@@ -4,23 +4,30 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work: with ``--gpus N > 1`` and no torchrun environment the process starts N fresh rank
+processes itself (``python -m torch.distributed.run`` as a CHILD, before anything here has touched the
+GPU) and relays rank 0's JSON line.
+
 A "step" is one complete ``RBM.train_epoch`` call (reference rbm.py:180-227) on the global batch:
-K1 -> K2 -> K1 -> K3 (+ epilogue kernels), called through the product's Python class exactly as
-``iDBN.train`` calls it (idbn.py:202).  Inputs (16 distinct synthetic binary 100x100 "dot" frames
-batches, density 0.1) are resident in HBM before the timed region.  With N>1 each rank holds a
-full parameter replica and 64 rows of a 64*N global batch; one exchange per step over RCCL (all-gather of the
-7 MB factor blocks by default, or all-reduce of the 60 MB packed statistics with --dp-mode allreduce); `value` counts batch-64 updates per second summed over the ranks (= N x global steps/s,
-weak scaling: 64 rows per GPU).
+K1 -> K2 -> K1 -> K3, called through the product's Python class exactly as ``iDBN.train`` calls it
+(idbn.py:202).  Inputs (16 distinct synthetic binary 100x100 "dot" frame batches, density 0.1) are resident
+in HBM before the timed region.  With N>1 each rank holds a full parameter replica and 64 rows of a 64*N
+global batch; one exchange per step over RCCL (all-gather of the factor blocks by default, the all-reduce of
+the packed statistics that north_star names is timed right after it and reported beside it); `value` counts
+batch-64 updates per second summed over the ranks (= N x global steps/s, weak scaling: 64 rows per GPU).
 
 One JSON line on rank 0.  `roofline` is for the dominant kernel (K3 assoc_update): algorithmic bytes
 16*V*H per launch over the HIP-event-measured mean launch time on the launch stream.
 `cpu_baseline` times the numpy oracle (a port of the reference arithmetic) on the same workload.
+`other_configs` times the other BASELINE.json configs (C2 stack, C3, C5) after the headline region.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,7 +35,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "multimodal-idbn_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
-
 
 
 def _cpu_share() -> int:
@@ -53,6 +59,26 @@ os.environ.setdefault("MKL_NUM_THREADS", str(CPU_SHARE))
 V, H, B = 10000, 1500, 64
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
+TRAFFIC_JSON = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _engine_source_sha() -> str:
+    """Hash of the kernel sources: stamps measurements that were taken in another run (PMC traffic)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "multimodal-idbn_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(max_seconds: float = 12.0, max_updates: int = 60):
@@ -64,7 +90,7 @@ def cpu_baseline(max_seconds: float = 12.0, max_updates: int = 60):
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        threads = os.cpu_count() or 1
+        threads = int(os.environ.get("OPENBLAS_NUM_THREADS", "1"))
     s = DrawStream(1)
     st = O.RBMState.create((s.normal((V, H)) / np.float32(100.0)).astype(np.float32), 0.1, 1e-4, 0.5,
                            dynamic_lr=True, final_momentum=0.95)
@@ -76,14 +102,115 @@ def cpu_baseline(max_seconds: float = 12.0, max_updates: int = 60):
         O.train_epoch(st, X, 0, 1, s)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "updates/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} CD-1 updates of the same 10000x1500 batch-64 workload, numpy/OpenBLAS oracle, "
+    return {"value": n / dt, "unit": "updates/s", "cores": int(threads), "kind": "port", "cpu_model": _cpu_model(),
+            "ms_per_update": 1e3 * dt / max(n, 1),
+            "sample": f"{n} CD-1 updates of the same 10000x1500 batch-64 workload, numpy/OpenBLAS oracle with {int(threads)} BLAS threads, "
                       f"{os.cpu_count()} host cpus visible, cgroup share {CPU_SHARE}"}
+
+
+def other_configs(dev):
+    """The other BASELINE.json configs through the product classes (1 GPU, synthetic data), after the headline region.
+    Bounds: the 1500<->500 layer, the joint RBM and the chains are launch / dependency-latency bound (weights of 3 MB and
+    0.5 MB sit in L2); C5's decode streams the 63 MB of image-stack weights once (HBM bound: 63 MB / t against 8 TB/s)."""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from imdbn import engine as E
+    from imdbn.models import RBM, iDBN, iMDBN
+
+    E.manual_seed(3)
+    params = {"LEARNING_RATE": 0.1, "WEIGHT_PENALTY": 1e-4, "INIT_MOMENTUM": 0.5, "FINAL_MOMENTUM": 0.95,
+              "LEARNING_RATE_DYNAMIC": True, "CD": 1, "JOINT_LEARNING_RATE": 0.04, "JOINT_CD": 1,
+              "JOINT_AUX_COND_STEPS": 30, "CROSS_GIBBS_STEPS": 50}
+    out = {}
+
+    def timeit(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    cwd = os.getcwd()
+    import tempfile
+    with tempfile.TemporaryDirectory() as scratch:      # iDBN.__init__ creates logs-idbn/ in cwd (reference idbn.py:115-116)
+        os.chdir(scratch)
+        try:
+            X = (torch.rand(64 * 8, 10000) > 0.9).float()
+            dl = DataLoader(TensorDataset(X, torch.zeros(len(X), 1)), batch_size=64)
+            d = iDBN([10000, 1500, 500], dict(params), dl, dl, dev)
+            xb = [b[0].to(dev) for b in dl]
+
+            def c2():      # the interleaved layer loop of iDBN.train (idbn.py:195-204) with its next-batch lookahead
+                for i, v in enumerate(xb):
+                    for li, r in enumerate(d.layers):
+                        r.train_epoch(v, 0, 1, CD=1, next_data=xb[(i + 1) % len(xb)] if li == 0 else None)
+                        v = r.forward(v)
+            t = timeit(c2, 4, 1) / len(xb)
+            out["C2_stack"] = {"ms_per_batch": 1e3 * t, "batches_per_s": 1.0 / t, "bound": "layer 1 HBM (see roofline); layer 2 + forwards launch/latency",
+                               "ref_cpu_ms_per_batch": 213.0}
+
+            jr = RBM(532, 256, 0.04, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=[(500, 532)]).to(dev)
+            z = torch.rand(64, 500, device=dev)
+            y = torch.eye(32, device=dev)[torch.randint(0, 32, (64,), device=dev)]
+            vp = torch.cat([z, y], 1)
+            vk = torch.zeros(64, 532, device=dev)
+            km = torch.zeros(64, 532, device=dev)
+            vk[:, 500:] = y
+            km[:, 500:] = 1
+
+            def c3_main():      # imdbn.py:590-611: one joint CD-1 update + one auxiliary clamped update (30 init steps)
+                jr.train_epoch(vp, 9, 20, CD=1)
+                jr.train_epoch_clamped(vk, km, 9, 20, CD=1, cond_init_steps=30, sample_h=False, sample_v=False,
+                                       reclamp_negative=False, aux_lr_mult=0.3, use_noisy_init=True)
+
+            def c3_warm():      # imdbn.py:566-588: two clamped updates
+                for _ in range(2):
+                    jr.train_epoch_clamped(vk, km, 0, 20, CD=1, cond_init_steps=30, sample_h=False, sample_v=False,
+                                           aux_lr_mult=0.3, use_noisy_init=True)
+            out["C3_joint_532x256"] = {"main_step_ms": 1e3 * timeit(c3_main, 20), "warmup_step_ms": 1e3 * timeit(c3_warm, 20),
+                                       "bound": "dependency latency (61 half steps on a 545 KB matrix)", "ref_cpu_main_ms": 30.7}
+
+            m = iMDBN([10000, 1500, 500], 256, params=dict(params), dataloader=dl, val_loader=dl, device=dev, num_labels=32)
+            m.z_class_mean = torch.rand(32, 500, device=dev)
+            z5 = torch.rand(256, 500, device=dev)
+            y5 = torch.eye(32, device=dev)[torch.randint(0, 32, (256,), device=dev)]
+            t5 = timeit(lambda: m._cross_reconstruct(z5, y5, steps=50), 10)
+            m.live_best_of_k, m.best_of_k = True, 16      # SURVEY 8d C5: K=16 with live free-energy selection
+            t5k = timeit(lambda: m._cross_reconstruct(z5, y5, steps=50), 10)
+            td = timeit(lambda: m.image_idbn.decode(z5), 10)
+            out["C5_cross_reconstruct_b256_s50"] = {"ms_default_k5_inert": 1e3 * t5, "ms_live_k16": 1e3 * t5k, "decode_ms": 1e3 * td,
+                                                    "decode_frac_hbm": 63.0e6 / td / (HBM_PEAK_GBS * 1e9),
+                                                    "bound": "chains: dependency latency; decode: HBM (63 MB of weights)", "ref_cpu_ms": 263.0}
+        finally:
+            os.chdir(cwd)
+    return out
 
 
 def _p50_max(t0, stamps):
     d = sorted(1e6 * (b - a) for a, b in zip([t0] + stamps[:-1], stamps))
     return [round(d[len(d) // 2], 1), round(d[-1], 1)] if d else None
+
+
+def _spawn_ranks(n: int, argv) -> int:
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: start the ranks as a child process tree
+    (this process has not imported torch or touched the GPU) and pass their output through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import __graft_entry__ as ge
+    ge.build()                      # once, here, before any rank exists
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print("[bench] starting ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def _under_profiler() -> bool:
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_ROOT", "HSA_TOOLS_LIB"))
 
 
 def main():
@@ -92,33 +219,47 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C3 / C5 timings after the headline region")
     ap.add_argument("--mode", default="parity", choices=["parity", "fast"])
     ap.add_argument("--ksplit-up", type=int, default=0)
     ap.add_argument("--ksplit-down", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning experiments)")
     ap.add_argument("--dp-full-planes", action="store_true", help="factor exchange: send the data plane as bf16 planes, not bits")
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand train_epoch the following batch (next_data=)")
-    ap.add_argument("--force-dp", action="store_true", help="take the stats/all-reduce/apply path even with one rank")
+    ap.add_argument("--force-dp", action="store_true", help="take the data-parallel path even with one rank")
     ap.add_argument("--no-k3-events", action="store_true", help="do not bracket K3 with HIP events in the timed region")
     ap.add_argument("--dp-mode", default="factors", choices=["factors", "allreduce"],
-                    help="data-parallel exchange: factor blocks (all-gather, ~7 MB/rank) or packed fp32 statistics (all-reduce, 60 MB)")
+                    help="data-parallel exchange of the headline region: factor blocks (all-gather) or packed fp32 statistics "
+                         "(all-reduce, 60 MB); the other one is timed after it and reported as dp_other_exchange")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank flow on one GPU)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn_ranks(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # The native library is built (or found fresh) BEFORE this process initialises the GPU or a profiler's preloaded
+    # library does: hipcc is never started from a GPU-initialised process.  Under a profiler, and on non-zero ranks,
+    # a stale library is an error / is waited for, never compiled here.
+    import __graft_entry__ as ge
+    if local == 0:
+        ge.build(compile_ok=not _under_profiler())
+    else:
+        ge.wait_built()
+
+    import torch
+    import torch.distributed as dist
+
     if args.backend != "nccl":
         local = local % torch.cuda.device_count()          # rehearsal: several ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 or args.force_dp:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
@@ -126,11 +267,6 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if world > 1:
-        dist.barrier()
     from imdbn import engine as E
     from imdbn.engine import native
     from imdbn.models import RBM
@@ -142,8 +278,6 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    if world > 1 or args.force_dp:
-        E.dp.enable(force=args.force_dp, mode=args.dp_mode, binary_data=not args.dp_full_planes)   # the synthetic batches are 0/1 images
 
     torch.manual_seed(0)
     rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
@@ -167,43 +301,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    try:
+    def timed_region(k3_events: bool):
+        """W warm-up steps, then exactly K steps between barrier + synchronize pairs; max over the ranks."""
         for i in range(args.warmup):
             step(i)
         sync()
-    except Exception as e:          # the factor exchange has preconditions (imdbn.engine.dp.enable); the all-reduce path has none
-        if not ((world > 1 or args.force_dp) and args.dp_mode == "factors"):
-            raise
-        print(f"[bench] rank {rank}: factor exchange failed ({type(e).__name__}: {e}); using the all-reduce exchange", file=sys.stderr, flush=True)
-        args.dp_mode = "allreduce"
-        E.dp.enable(force=args.force_dp, mode="allreduce", binary_data=not args.dp_full_planes)
-        for i in range(args.warmup):
-            step(i)
+        if k3_events:
+            eng.profile(True)
+        t0 = time.perf_counter()
+        stamps = []
+        for i in range(args.steps):
+            loss = step(i)
+            stamps.append(time.perf_counter())
+        t_enq = time.perf_counter() - t0          # host time to enqueue all steps (== dt when host-bound)
         sync()
-    if world == 1 and not args.no_k3_events:
-        eng.profile(True)
-    t0 = time.perf_counter()
-    stamps = []
-    for i in range(args.steps):
-        loss = step(i)
-        stamps.append(time.perf_counter())
-    t_enq = time.perf_counter() - t0          # host time to enqueue all steps (== dt when host-bound)
-    sync()
-    dt = time.perf_counter() - t0
-    k3_ms, k3_n = (eng.profile_read() if world == 1 else (0.0, 0))
-    if world == 1:
-        eng.profile(False)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(loss).item(), "loss is not finite"
-    replicas_identical = None
-    if world > 1:      # after the timed region: every rank applied the same update, so the replicas must agree bit for bit
+        dt = time.perf_counter() - t0
+        k3 = eng.profile_read() if k3_events else (0.0, 0)
+        if k3_events:
+            eng.profile(False)
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert torch.isfinite(loss).item(), "loss is not finite"
+        return dt, t_enq, stamps, t0, k3, float(loss)
+
+    # Any failure below (an engine error, a HIP or RCCL error) ends the run with a non-zero exit code: no fallback to another
+    # exchange in a process that has seen a GPU error, and no rank ever switches collectives on its own.
+    if use_dp:
+        E.dp.enable(force=args.force_dp, mode=args.dp_mode, binary_data=not args.dp_full_planes)   # the synthetic batches are 0/1 images
+    dt, t_enq, stamps, t0, (k3_ms, k3_n), loss = timed_region(world == 1 and not use_dp and not args.no_k3_events)
+
+    def replicas_identical():
+        if world == 1:
+            return None      # every rank applied the same update, so the replicas must agree bit for bit
         chk = torch.stack([rbm.W.data.double().sum(), rbm.W.data.double().abs().sum(), rbm.hid_bias.data.double().sum()])
         allc = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(allc, chk)
-        replicas_identical = all(torch.equal(allc[0], c) for c in allc)
+        return all(torch.equal(allc[0], c) for c in allc)
+
+    def exchange_name(mode):
+        if mode != "factors":
+            return "allreduce (packed fp32 statistics, one all-reduce per step)"
+        return "factors (all-gather; wire form: " + ("sample as bits)" if args.dp_full_planes else "data and sample as bits)")
+
+    ident = replicas_identical()
+    other_exchange = None
+    if use_dp:      # the other exchange, same K steps, reported beside the headline one
+        other = "allreduce" if args.dp_mode == "factors" else "factors"
+        E.dp.enable(force=args.force_dp, mode=other, binary_data=not args.dp_full_planes)
+        dt2, _, _, _, _, loss2 = timed_region(False)
+        other_exchange = {"dp_exchange": exchange_name(other), "value": world * args.steps / dt2, "unit": "updates/s",
+                          "ms_per_step": 1e3 * dt2 / args.steps, "final_loss": loss2, "replicas_identical": replicas_identical()}
 
     if rank == 0:
         # unit = one batch-64 CD-1 update; every rank processes one per step (the step updates the shared weights
@@ -218,39 +367,41 @@ def main():
             "config": {"workload": "BASELINE configs[1] layer 1: RBM 10000<->1500 train_epoch, CD-1, batch 64 per GPU, "
                                    "fp32 master weights, lr 0.1 wd 1e-4 mom 0.5",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "dp_exchange": ((args.dp_mode + ("" if args.dp_mode != "factors" else (" (wire form: sample as bits)" if args.dp_full_planes else " (wire form: data and sample as bits)")))
-                                       if (world > 1 or args.force_dp) else None),
+                       "dp_exchange": exchange_name(args.dp_mode) if use_dp else None,
                        "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
-                       "final_loss": float(loss), "replicas_identical": replicas_identical},
+                       "final_loss": loss, "replicas_identical": ident},
             "global_steps_per_s": args.steps / dt,
             "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
             "host_enqueue_us_p50_max": _p50_max(t0, stamps),
             "frac_hbm_roofline_whole_step": (ups / world) * 16.0 * V * H / (HBM_PEAK_GBS * 1e9),
             "frac_bf16_mfma_roofline_whole_step": (ups / world) * 10.0 * B * V * H / (BF16_PEAK_TFLOPS * 1e12),
+            "dp_other_exchange": other_exchange,
         }
-        if world == 1 and k3_n > 0:
+        if k3_n > 0:
             avg_s = 1e-3 * k3_ms / k3_n
             ach = 16.0 * V * H / avg_s / 1e9
-            traffic, tsrc = None, None        # HBM bytes per launch from the committed PMC passes of this same command
+            # HBM bytes per launch come from rocprofv3 --pmc passes of this same command (separate runs: counters cannot be
+            # collected from inside the process); the file carries the hash of the kernel sources it was measured on
+            traffic, tsrc, stale = None, None, None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                pm = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
                 for k, d in pm["kernels"].items():
                     if "assoc_update" in k:
-                        traffic, tsrc = d["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)"
+                        traffic, tsrc = d["hbm_bytes_per_launch"], TRAFFIC_JSON + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                stale = pm.get("engine_source_sha") != _engine_source_sha()
             except Exception:
                 pass
             out["roofline"] = {"kernel": "assoc_update (K3)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                               "traffic_measured_on_other_sources": stale,
                                "avg_launch_us": 1e6 * avg_s, "launches": k3_n,
                                "algorithmic_bytes_per_launch": 16 * V * H}
         else:
             out["roofline"] = None
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        else:
-            out["cpu_baseline"] = None
+        out["other_configs"] = other_configs(dev) if (world == 1 and not use_dp and not args.no_other_configs) else None
+        out["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out), flush=True)
-    if world > 1 or args.force_dp:
+    if use_dp:
         dist.destroy_process_group()
 
 

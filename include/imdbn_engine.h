@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IMDBN_ABI_VERSION 1
+#define IMDBN_ABI_VERSION 2
 
 /* error codes (negative) */
 #define IMDBN_E_INVALID   (-1)   /* bad argument (shape, null pointer, alignment) */
@@ -118,6 +118,10 @@ typedef struct imdbn_cd_opts {
     int64_t ld_next;
     int32_t next_slot;      /* 1 or 2: where to put it (must differ from data_slot) */
     int32_t data_slot;      /* 0: prepare `data` now (default); 1 / 2: `data` was prefetched into that slot */
+    /* -- 1: the caller asserts that every element of `data` is exactly 0 or 1 (binary images): the positive phase then reads
+     * the batch as a bit plane (imdbn_rbm_cd_step / _cd_stats / _cd_factors).  The assertion is checked on the device; a batch
+     * that is not binary turns the update into NaN instead of being silently truncated.  0: no assumption. */
+    int32_t data_binary;
 } imdbn_cd_opts;
 
 /* ---- plumbing ------------------------------------------------------------------------- */

@@ -153,7 +153,7 @@ __device__ __forceinline__ int operand_terms(const int* map, int ncb, int P, int
     cb1 = min(cb1, ncb);
     const int w = cb1 - cb0, n = w * P;
     int any = 0;
-    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) any |= map[(i / w) * ncb + cb0 + (i % w)];
+    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) any |= map[(i / w) * ncb + cb0 + (i % w)] & 1;      // bit 0: inexact in bf16
     return __any(any) ? 3 : 1;
 }
 

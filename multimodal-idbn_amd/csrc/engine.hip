@@ -17,6 +17,7 @@
 #include "kernels_ew.hpp"
 #include "kernels_gemm.hpp"
 #include "kernels_chain.hpp"
+#include "kernels_stream.hpp"
 
 using namespace imdbn;
 
@@ -35,6 +36,8 @@ int g_min_rank_loop = 2;  // apply_factors: rank blocks from which the single-la
 int g_no_prefetch = 0;   // testing: ignore imdbn_cd_opts.next_data
 int g_no_bits = 0;  // testing: never use the bit-packed hidden operand
 int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
+int g_no_k1s = 0;  // testing: never use the LDS-DMA streaming K1 for binary operands (k1_stream)
+int g_k1s_ks = 0;  // tuning: K slices of k1_stream (0 = automatic)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
@@ -92,7 +95,9 @@ struct Layout {
     bf16_t* vis_tr[2];
     bf16_t* hid_rm;
     bf16_t* hid_tr[2];
-    uint32_t* hid_bits; int ldbits;      // bit-packed sampled hidden states [Bp][ldbits]
+    uint8_t* hid_bits; int ldbits;       // bit plane of the sampled hidden states, byte-major [Hpad64/8][Bp]
+    uint8_t* vis_bits[2];                // bit planes of the visible operands (0: data, 1: negative-phase sample), [Vpad64/8][Bp]
+    uint8_t* pf_bits[2];                 // ... of the prefetch slots
     float* partial;
     float* f_h;
     float* f_vp;
@@ -105,6 +110,7 @@ struct Layout {
     ChainRec* chain_recs;   // per-step schedule of the row-parallel chain kernel
     bf16_t* k4_planes; int64_t k4_plane_stride;      // fragment-ordered bf16 weight planes [2 directions][3 terms]
     int down_tr;            // visible rows per block of the fused K2 (<= 32): balances the row tiles over the CUs
+    int k1s_tiles, k1s_ks, k1s_kchunk; int* k1s_cnt;      // k1_stream: 32-column tiles, K slices, arrival counters [Bp/64][tiles]
     size_t bytes;
 };
 
@@ -126,7 +132,7 @@ int plan_down_rows(int V) {
     if (g_down_tr > 0) return g_down_tr;
     const int cus = cu_count();
     int best = 32, best_cost = 1 << 30;
-    for (int tr = 32; tr >= 16; tr -= 4) {
+    for (int tr = 32; tr >= 16; tr -= 8) {                  // multiples of 8: the epilogue writes the sample's bit plane byte-wise
         const int cost = cdiv(cdiv(V, tr), cus) * tr;       // rows streamed by the busiest CU
         if (cost < best_cost) { best_cost = cost; best = tr; }
     }
@@ -175,9 +181,19 @@ Layout make_layout(int V, int H, int B, char* base) {
     for (int i = 0; i < 2; ++i) L.vis_rm[i] = (bf16_t*)take((size_t)3 * L.Bp * L.Vpad * 2);
     L.hid_rm = (bf16_t*)take((size_t)3 * L.Bp * L.Hpad * 2);
     L.ldbits = 2 * cdiv(L.Hpad, 64);
-    L.hid_bits = (uint32_t*)take((size_t)L.Bp * L.ldbits * 4);
-    const size_t pf = std::max((size_t)L.up.ks * L.Bp * H, (size_t)L.down.ks * L.Bp * V);
+    L.hid_bits = (uint8_t*)take((size_t)L.Bp * rup(H, 64) / 8);
+    for (int i = 0; i < 2; ++i) L.vis_bits[i] = (uint8_t*)take((size_t)L.Bp * rup(V, 64) / 8);
+    {   // k1_stream: ~one block per CU; a K slice is a multiple of 64 rows and at most K1S_MAX_KCHUNK (its bits sit in LDS)
+        L.k1s_tiles = cdiv(H, 32);
+        int ks = g_k1s_ks > 0 ? g_k1s_ks : std::max(1, (int)((double)cu_count() / (double)(L.k1s_tiles * mb) + 0.5));
+        ks = std::min(ks, cdiv(L.Vpad, 64));
+        ks = std::max(ks, cdiv(L.Vpad, K1S_MAX_KCHUNK));
+        L.k1s_kchunk = rup(cdiv(L.Vpad, ks), 64);
+        L.k1s_ks = cdiv(L.Vpad, L.k1s_kchunk);
+    }
+    const size_t pf = std::max(std::max((size_t)L.up.ks * L.Bp * H, (size_t)L.down.ks * L.Bp * V), (size_t)L.k1s_ks * L.Bp * 32 * L.k1s_tiles);
     L.partial = (float*)take(pf * 4);
+    L.k1s_cnt = (int*)take((size_t)mb * L.k1s_tiles * 4);
     L.f_h = (float*)take((size_t)L.Bp * H * 4);
     L.f_vp = (float*)take((size_t)L.Bp * V * 4);
     for (int i = 0; i < 2; ++i) L.f_v[i] = (float*)take((size_t)L.Bp * V * 4);
@@ -187,6 +203,7 @@ Layout make_layout(int V, int H, int B, char* base) {
         L.pf_tr[i] = (bf16_t*)take((size_t)3 * V * L.Bp * 2);
         L.pf_flags[i] = (int*)take((size_t)L.P * cdiv(L.Vpad, 64) * 4);
         L.pf_cs[i] = (float*)take((size_t)L.P * V * 4);
+        L.pf_bits[i] = (uint8_t*)take((size_t)L.Bp * rup(V, 64) / 8);
     }
     L.k4_plane_stride = 0; L.k4_planes = nullptr;
     if (V <= 1024 && H <= 1024) {
@@ -285,6 +302,7 @@ void use_slot(Layout& L, int slot) {
     std::swap(L.vis_tr[0], L.pf_tr[slot - 1]);
     std::swap(L.flags, L.pf_flags[slot - 1]);
     std::swap(L.cs_vpos, L.pf_cs[slot - 1]);
+    std::swap(L.vis_bits[0], L.pf_bits[slot - 1]);
 }
 
 int setup(Ctx& c, int B, void* ws, size_t ws_bytes) {
@@ -298,7 +316,13 @@ int setup(Ctx& c, int B, void* ws, size_t ws_bytes) {
 }
 
 // An activation operand in row-major form: pointer + static term count (0 = look at flag)
-struct OpIn { const bf16_t* rm; int terms; const int* flag; };
+// bits / binary: the operand also exists as a bit plane; binary = 1: it is 0/1 by construction (a sample), 2: the caller
+// says so (checked on the device against the exactness map `flag`)
+struct OpIn { const bf16_t* rm; int terms; const int* flag; const uint8_t* bits = nullptr; int binary = 0; };
+
+bool vec4_weights(const imdbn_rbm_desc* d) {
+    return d->H % 4 == 0 && d->H >= 4 && d->ldw % 4 == 0 && (((uintptr_t)d->W) & 15) == 0;
+}
 
 void base_finish_args(Ctx& c, bool up, FinishArgs& f) {
     const Layout& L = c.L;
@@ -346,6 +370,33 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         HIPCHK(hipGetLastError());
         return 0;
     }
+    // hidden samples (exactly 0/1, not mixed with clamped values) also leave as a bit plane for the fused K2
+    const bool want_hbits = up && f.op.rm == L.hid_rm && f.rm_src == 2 && f.vmode == 1 && !f.clamp && f.n_groups == 0 && !f.logits_only;
+    if (up && in.bits && in.binary && vec4_weights(d) && !g_no_k1s && !f.logits_only) {
+        // binary visible operand: weights stream through LDS by LDS-DMA, split-K combined by the last arriver, epilogue fused
+        K1sArgs a;
+        memset(&a, 0, sizeof(a));
+        a.W = d->W; a.ldw = d->ldw; a.K = L.V; a.N = L.H;
+        a.abits = in.bits; a.Bp = L.Bp;
+        a.aflag = in.binary == 2 ? in.flag : nullptr; a.ncb = cdiv(L.Vpad, 64); a.P = L.P;
+        a.slabs = L.partial; a.counters = L.k1s_cnt; a.kchunk = L.k1s_kchunk; a.ks = L.k1s_ks;
+        f.dbg = 0;
+        f.op.bits = want_hbits ? L.hid_bits : nullptr; f.op.bits_shape = 1; f.op.bits_cols = 32;
+        if (f.op.rm == L.hid_rm) c.hid_bits_ok = want_hbits;
+        if (want_hbits && !g_no_bits) f.op.rm = nullptr, f.rm_src = 0;      // the fused K2 reads the bit plane, nobody reads the bf16 form
+        const size_t lds = (size_t)4 * K1S_RING + (size_t)8 * a.kchunk + 16;
+        static bool attr_done = false;
+        if (!attr_done) {
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK + 16));
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK + 16));
+            attr_done = true;
+        }
+        dim3 grid(L.k1s_tiles, a.ks, mb);
+        if (c.nw == 3) hipLaunchKernelGGL(k1_stream<3>, grid, dim3(256), lds, c.s, a, f);
+        else           hipLaunchKernelGGL(k1_stream<1>, grid, dim3(256), lds, c.s, a, f);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (up) {
         const int64_t ats = (int64_t)L.Bp * L.Vpad;
         const bool fast = L.up4 && d->ldw % 4 == 0 && (((uintptr_t)d->W) & 15) == 0;
@@ -371,8 +422,10 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         // (4096, 7168]) do not end on a multiple of 16 by themselves; found by tools/stress_parity.py.
         dim3 grid(cdiv(L.Vpad, L.down_tr), 1, mb);
         f.dbg = g_dbg;
+        if (f.op.bits && (L.down_tr % 8 != 0 || f.n_groups > 0 || f.vmode == 0)) f.op.bits = nullptr;      // not a 0/1 plane the epilogue can write byte-wise
+        f.op.bits_shape = 1; f.op.bits_cols = L.down_tr;
         // sampled hidden states left by `finish` in bit-packed form: 16x less activation traffic per block
-        const uint32_t* abits = (c.hid_bits_ok && in.rm == L.hid_rm && in.terms == 1 && !g_no_bits) ? L.hid_bits : nullptr;
+        const uint8_t* abits = (c.hid_bits_ok && in.rm == L.hid_rm && in.terms == 1 && !g_no_bits) ? L.hid_bits : nullptr;
         const int64_t ats = (int64_t)L.Bp * L.Hpad;
         const bool vec4 = (d->ldw % 4 == 0) && (((uintptr_t)d->W & 15) == 0) && (L.H % 4 == 0) && L.H >= 4;
         if ((int)((grid.x + IMDBN_MAX_GROUPS) * grid.z) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
@@ -409,10 +462,8 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
     dim3 fgrid(cdiv(f.N, 64), L.P);
     if ((int)(fgrid.x * fgrid.y) + IMDBN_MAX_GROUPS * (L.Bp / 64) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
     f.dbg = g_dbg;
-    // hidden samples (exactly 0/1, not mixed with clamped values) also leave in bit-packed form for the fused K2
-    const bool bits = up && f.op.rm == L.hid_rm && f.rm_src == 2 && f.vmode == 1 && !f.clamp && f.n_groups == 0 && !f.logits_only;
-    f.op.bits = bits ? L.hid_bits : nullptr; f.op.ldbits = L.ldbits;
-    if (up && f.op.rm == L.hid_rm) c.hid_bits_ok = bits;
+    f.op.bits = want_hbits ? L.hid_bits : nullptr; f.op.bits_shape = 0;
+    if (up && f.op.rm == L.hid_rm) c.hid_bits_ok = want_hbits;
     hipLaunchKernelGGL(finish, fgrid, dim3(256), 0, c.s, f);
     HIPCHK(hipGetLastError());
     if (f.n_groups > 0 && !f.logits_only) {
@@ -428,9 +479,11 @@ int n_loss_used(const Ctx& c, bool up) {
 
 // caller fp32 tensor -> operand forms in the workspace
 int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_t* tr, int* flag,
-         float* colsum = nullptr, int terms = 3) {
+         float* colsum = nullptr, int terms = 3, uint8_t* bits = nullptr) {
     PrepArgs p;
     memset(&p, 0, sizeof(p));
+    p.op.bits = bits; p.op.bits_shape = 0;
+    p.zero = c.L.k1s_cnt; p.n_zero = (c.L.Bp / 64) * c.L.k1s_tiles;      // first launch of a call: arrival counters of k1_stream
     p.in = in; p.ld = ld; p.B = c.L.B; p.Bp = c.L.Bp; p.N = N;
     p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = terms; p.op.Bp = c.L.Bp;
     p.op.tr = tr; p.op.tr_ts = (int64_t)N * c.L.Bp; p.op.tr_terms = terms;
@@ -524,7 +577,9 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
     const Layout& L = c.L;
     const int B = L.B;
     if (o->cd_k < 1) return fail(IMDBN_E_INVALID, "CD=%d (the reference needs CD>=1, rbm.py:204-209)", o->cd_k);
-    if (!c.data_prepped) CHK(prep(c, data, ldd, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], L.flags, L.cs_vpos));
+    if (!c.data_prepped) CHK(prep(c, data, ldd, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], L.flags, L.cs_vpos, 3, L.vis_bits[0]));
+    // the visible sample of the negative phase leaves the fused K2 as a bit plane too when its tiles are whole bytes wide
+    const bool vbits = c.d->n_groups == 0 && L.down_tr % 8 == 0;
     // positive phase: P+ = up(data); h = 1[P+ > U]
     {
         FinishArgs f = new_finish();
@@ -532,7 +587,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
         f.op.rm = L.hid_rm; f.op.rm_terms = 1; f.rm_src = 2;
         f.op.tr = L.hid_tr[0]; f.op.tr_terms = c.rt; f.tr_src = 1;
         f.colsum_part = L.cs_hpos; f.colsum_src = 1;
-        CHK(prop(c, true, OpIn{L.vis_rm[0], c.nw == 1 ? 1 : 0, L.flags}, f));
+        CHK(prop(c, true, OpIn{L.vis_rm[0], c.nw == 1 ? 1 : 0, L.flags, L.vis_bits[0], o->data_binary ? 2 : 0}, f));
     }
     for (int it = 0; it < o->cd_k; ++it) {
         const bool last = (it == o->cd_k - 1);
@@ -546,6 +601,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
             f.op.tr = L.vis_tr[1]; f.op.tr_terms = 1; f.tr_src = 2;
             f.colsum_part = L.cs_vneg; f.colsum_src = 2;
             f.loss_ref = data; f.ld_ref = ldd; f.loss_src = 1; f.loss_part = L.loss_part;
+            if (vbits) f.op.bits = L.vis_bits[1];
             CHK(prop(c, false, OpIn{L.hid_rm, 1, nullptr}, f, it == 0 ? next : nullptr));
         }
         {   // h_prob = up(v); h = 1[h_prob > U]  (the last draw is consumed but unused, rbm.py:208)
@@ -554,7 +610,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
             if (!last) { f.vmode = 1; f.uni = u; f.op.rm = L.hid_rm; f.op.rm_terms = 1; f.rm_src = 2; }
             f.op.tr = L.hid_tr[1]; f.op.tr_terms = c.rt; f.tr_src = 1; f.op.tr_negate = 1;
             f.colsum_part = L.cs_hneg; f.colsum_src = 1;
-            CHK(prop(c, true, OpIn{L.vis_rm[1], 1, nullptr}, f));
+            CHK(prop(c, true, OpIn{L.vis_rm[1], 1, nullptr, vbits ? L.vis_bits[1] : nullptr, 1}, f));
         }
     }
     return 0;
@@ -753,6 +809,8 @@ int imdbn_set_option(const char* name, int value) {
     else if (!strcmp(name, "no_rank_acc")) g_no_rank_acc = value;
     else if (!strcmp(name, "min_rank_loop")) g_min_rank_loop = value;
     else if (!strcmp(name, "dbg")) g_dbg = value;
+    else if (!strcmp(name, "no_k1s")) g_no_k1s = value;
+    else if (!strcmp(name, "k1s_ks")) g_k1s_ks = std::max(0, value);
     else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
     else if (!strcmp(name, "no_fused_up")) g_no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);
@@ -907,6 +965,7 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
         pn.op.rm = L.pf_rm[t]; pn.op.ldrm = L.Vpad; pn.op.rm_ts = (int64_t)L.Bp * L.Vpad; pn.op.rm_terms = 3; pn.op.Bp = L.Bp;
         pn.op.tr = L.pf_tr[t]; pn.op.tr_ts = (int64_t)L.V * L.Bp; pn.op.tr_terms = 3;
         pn.flag = L.pf_flags[t]; pn.colsum_part = L.pf_cs[t];
+        pn.op.bits = L.pf_bits[t]; pn.op.bits_shape = 0;
     }
     if (o->data_slot) { use_slot(c.L, o->data_slot); c.data_prepped = true; }
     CHK(cd_phases(c, data, ldd, o, next_rows > 0 ? &pn : nullptr));

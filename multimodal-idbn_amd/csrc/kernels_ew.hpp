@@ -24,10 +24,23 @@ struct OperandOut {
     bf16_t* rm; int64_t rm_ts; int ldrm; int rm_terms; int Bp;
     bf16_t* tr; int64_t tr_ts; int tr_terms;             // transposed  [t][N][Bp]
     int tr_negate;                                       // store the transposed planes with the sign flipped
-    // bit-packed form of an exactly-{0,1} operand (sampled states): bits[(k >> 5)*Bp + b] bit (k & 31) (word-major: a wave's loads are contiguous); written
-    // only by `finish` (a wave = 64 consecutive columns), read by the fused K2 instead of the 16x larger bf16 form
-    uint32_t* bits; int ldbits;
+    // bit-packed form of an exactly-{0,1} operand (sampled states, binary data), BYTE-major: bits[(k >> 3)*Bp + b] bit (k & 7):
+    // the 8 k-values of one MFMA fragment lane are one byte, any 8-column-aligned tile can write its part, and a wave's loads
+    // of one K block are contiguous.  16x smaller than the bf16 form.  bits_shape: how the lanes of a wave map to columns in
+    // the writing kernel -- 0: 64 consecutive columns (finish, prep), 1: 32 consecutive columns x 2 row groups (lanes >= 32)
+    uint8_t* bits; int bits_shape; int bits_cols;      // bits_cols (shape 1): valid columns of the 32-column run (multiple of 8)
 };
+
+// row `b` of a 0/1 operand for the columns the wave covers -> bit plane (one byte per 8 columns).  nz = this lane's value != 0.
+__device__ __forceinline__ void store_bits_row(const OperandOut& o, bool nz, int col, int b, bool row_ok) {
+    const unsigned long long m = __ballot(nz ? 1 : 0);
+    const int lane = threadIdx.x & 63;
+    int j, shift, colbase;
+    bool w;
+    if (o.bits_shape == 0) { j = lane; w = lane < 8; shift = 8 * lane; colbase = col - lane; }
+    else { j = lane & 31; w = j < (o.bits_cols >> 3); shift = 32 * (lane >> 5) + 8 * j; colbase = col - j; }
+    if (w && row_ok) o.bits[(int64_t)((colbase >> 3) + j) * o.Bp + b] = (uint8_t)((m >> (shift & 63)) & 0xFFull);
+}
 
 // bf16 terms of R values: terms == 1 -> one round-to-nearest bf16 (exact for samples / exactly-bf16 data),
 // terms == 3 -> hi/mid/lo truncation split (fp32-exact products).  Computed ONCE per element and shared by
@@ -261,15 +274,9 @@ __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, 
     }
     // (softmax-group columns of a staged tile are flushed with whatever the stage holds and then rewritten by
     //  finish_groups, which runs after this kernel)
-    if (a.op.bits) {                  // block-uniform; lanes of the wave = 64 consecutive columns starting at a multiple of 64
+    if (a.op.bits) {                  // block-uniform; the wave's lanes cover aligned runs of 64 (or 2 x 32) consecutive columns
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const unsigned long long m = __ballot(xf[i] != 0.f);
-            if ((threadIdx.x & 63) == 0 && b0 + i < a.Bp) {
-                uint32_t* q = a.op.bits + (int64_t)((col >> 6) << 1) * a.Bp + (b0 + i);      // word-major: [k >> 5][Bp]
-                q[0] = (uint32_t)m; q[a.Bp] = (uint32_t)(m >> 32);
-            }
-        }
+        for (int i = 0; i < R; ++i) store_bits_row(a.op, xf[i] != 0.f, col, b0 + i, b0 + i < a.Bp);
     }
     return lsum;
 }
@@ -504,9 +511,12 @@ struct PrepArgs {
     const float* in; int64_t ld; int B, Bp, N;
     int mix; const float* mask; int64_t ldm; DrawSrc uni;
     float* out_f32; int64_t ldo;
-    OperandOut op; int* flag;      // exactness map [Bp/8][ceil(N/64)]: 1 = some element of the tile needs 3 bf16 terms
+    OperandOut op; int* flag;      // exactness map [Bp/8][ceil(N/64)], per tile of 8 rows x 64 columns: bit 0 = some element needs
+                                   // 3 bf16 terms, bit 1 = some element is neither 0 nor 1 (the bit plane op.bits does not describe it)
     float* colsum_part;            // [Bp/8][N] column sums over each 8-row group (sum data, rbm.py:223)
+    int* zero; int n_zero;         // words block (0,0) of prep_operand clears (arrival counters of the split-K kernels of this call)
 };
+constexpr int FLAG_INEXACT = 1, FLAG_NONBINARY = 2;
 
 // block = 64 columns x 8 rows, 256 threads = 64 columns x 4 row pairs: all loads unconditional (clamped) and
 // issued before any use; the K16-blocked form leaves through the LDS stage as 16-B stores.
@@ -518,6 +528,8 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
     const int col = blockIdx.x * 64 + c;
     const int g0 = blockIdx.y * 8, b0 = g0 + 2 * kq;
     const int cc = min(col, a.N - 1);
+    if (a.zero && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < a.n_zero; i += 256) a.zero[i] = 0;
     float v[2], m[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -527,7 +539,7 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
     }
     float x[2];
     float csum = 0.f;
-    bool inexact = false;
+    bool inexact = false, nonbin = false;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int b = b0 + i;
@@ -538,9 +550,11 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
         x[i] = live ? t : 0.f;
         csum += x[i];
         inexact |= (__float_as_uint(x[i]) & 0xFFFFu) != 0u;
+        nonbin |= (x[i] != 0.f && x[i] != 1.0f);
+        if (a.op.bits) store_bits_row(a.op, x[i] != 0.f, col, b, b < a.Bp);
     }
-    const bool any = __any(inexact ? 1 : 0) != 0;
-    if (c == 0) fl[kq] = any ? 1 : 0;
+    const bool any = __any(inexact ? 1 : 0) != 0, anyb = __any(nonbin ? 1 : 0) != 0;
+    if (c == 0) fl[kq] = (any ? FLAG_INEXACT : 0) | (anyb ? FLAG_NONBINARY : 0);
     cs[kq][c] = csum;
     const RmStage stg{rmst, 4, 8, (int)blockIdx.x * 64, g0};
     store_forms<2>(a.op, x, true, true, b0, col, a.N, a.Bp, &stg);
@@ -580,17 +594,19 @@ __device__ __forceinline__ void prep_item_body(const PrepArgs& a, int tx, int mb
     for (int hf = 0; hf < 2; ++hf) {
         const int b0 = mb * 64 + 16 * kq + 8 * hf, by = b0 >> 3;
         float x[8];
-        bool inexact = false;
+        bool inexact = false, nonbin = false;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             x[i] = (col < a.N && b0 + i < a.B) ? v[8 * hf + i] : 0.f;
             inexact |= (__float_as_uint(x[i]) & 0xFFFFu) != 0u;
+            nonbin |= (x[i] != 0.f && x[i] != 1.0f);
+            if (a.op.bits) store_bits_row(a.op, x[i] != 0.f, col, b0 + i, true);
         }
         // the order of prep_operand: four row pairs, combined left to right
         const float csum = (((0.f + x[0] + x[1]) + (0.f + x[2] + x[3])) + (0.f + x[4] + x[5])) + (0.f + x[6] + x[7]);
-        const bool any = __any(inexact ? 1 : 0) != 0;               // the wave = this group's 64 columns
+        const bool any = __any(inexact ? 1 : 0) != 0, anyb = __any(nonbin ? 1 : 0) != 0;      // the wave = this group's 64 columns
         store_forms<8>(a.op, x, true, true, b0, col, a.N, a.Bp, &stg);
-        if (a.flag && c == 0) a.flag[by * ntx + tx] = any ? 1 : 0;
+        if (a.flag && c == 0) a.flag[by * ntx + tx] = (any ? FLAG_INEXACT : 0) | (anyb ? FLAG_NONBINARY : 0);
         if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)by * a.N + col] = csum;
     }
     lds_barrier();

@@ -337,7 +337,7 @@ template <bool UP, int NW, bool VEC4, int NA, bool BITS = false>
 __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int64_t ldw, int K, int N,
                                                 const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
                                                 const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33], int TR,
-                                                const uint32_t* __restrict__ abits, int ldbits,
+                                                const uint8_t* __restrict__ abits, int ldbits,
                                                 int bx, int bz, int nbx /* tile (bx of nbx, batch chunk bz): blockIdx in the plain kernels */) {
     static_assert(!BITS || NA == 1, "bit-packed activations are single-term");
     constexpr int D = 4;                     // operand ring depth: D x (2 KB weights + activations) in flight per wave
@@ -371,11 +371,9 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
             for (int j = 0; j < 8; ++j) o.wv[j] = wrow[min(k0 + j, K - 1)];
         }
         if constexpr (BITS) {
-            // one dword = this row's bits of K columns 32*(kb>>5) .. +31; byte 2*((kb>>4)&1) + hh is this lane's fragment
-            o.ab[0] = abits[(int64_t)(kbc >> 5) * fa.Bp + arow0];
-            o.ab[1] = abits[(int64_t)(kbc >> 5) * fa.Bp + arow1];
-            const int sh = 8 * (2 * ((kbc >> 4) & 1) + hh);
-            o.ab[0] = (o.ab[0] >> sh) & 0xFFu; o.ab[1] = (o.ab[1] >> sh) & 0xFFu;
+            // byte-major bit plane: byte (k >> 3) of a batch row = the 8 k-values of this lane's fragment
+            o.ab[0] = abits[(int64_t)((kbc >> 3) + hh) * fa.Bp + arow0];
+            o.ab[1] = abits[(int64_t)((kbc >> 3) + hh) * fa.Bp + arow1];
         } else {
 #pragma unroll
             for (int ta = 0; ta < NA; ++ta) {
@@ -479,7 +477,7 @@ template <int NW, bool VEC4, int NAK, bool BITS>
 __global__ __launch_bounds__(256, 2) void gemm_down_fused(
     const float* __restrict__ W, int64_t ldw, int K, int N,
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
-    const FinishArgs fa, int tile_rows, const uint32_t* __restrict__ abits, int ldbits) {
+    const FinishArgs fa, int tile_rows, const uint8_t* __restrict__ abits, int ldbits) {
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
     stamp((fa.dbg & 128) != 0, blockIdx.z * gridDim.x + blockIdx.x, 0);
@@ -506,7 +504,7 @@ template <int NW, bool BITS>
 __global__ __launch_bounds__(256, 2) void gemm_down_fused_next(
     const float* __restrict__ W, int64_t ldw, int K, int N,
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
-    const FinishArgs fa, int tile_rows, const uint32_t* __restrict__ abits, int ldbits, const PrepArgs next, int main_nbx) {
+    const FinishArgs fa, int tile_rows, const uint8_t* __restrict__ abits, int ldbits, const PrepArgs next, int main_nbx) {
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
     if ((int)blockIdx.x >= main_nbx) {

@@ -1,0 +1,195 @@
+// kernels_stream.hpp -- round-2 propagation kernels for BINARY activations: the weight matrix streams through LDS by
+// LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, no staging registers) and the activations are bit planes.
+//
+//   k1_stream   K1  h = sigmoid(v W + c) for a 0/1 visible operand (the negative-phase sample always; the data when the
+//                   caller says they are binary): 32-column tiles x a few K slices, split-K combined by the LAST block to
+//                   arrive at a tile (no spin, no second launch), epilogue fused                    (rbm.py:92, :199-208)
+//
+// Why 32-column tiles: the split-K slab volume is (#blocks) x 64 x (columns per block) x 4 B.  With the 128-column tiles
+// of gemm_up4_partial, 240 blocks leave 7.7 MB of slabs (20 K slices) for a second launch (`finish`, 7 us) to re-read.
+// LDS-DMA decouples the load shape from the MFMA fragment shape: a 32-column tile is read as 8 rows x 128 B per
+// instruction at the same rate as 512-B segments (tools/membench2.hip: 9.4-10.3 us for the 60 MB of a 10000 x 1500
+// layer against 9.0-9.4), needs only 5 K slices (1.9 MB of slabs) and the last arriver of a tile sums 5 x 8 KB.
+#pragma once
+#include "common.hpp"
+#include "kernels_ew.hpp"
+#include "kernels_gemm.hpp"
+
+namespace imdbn {
+
+// LDS-DMA of 16 B per lane: lane i's bytes land at LDS[lds_off + 16 i].  M0 (the LDS base) is saved and restored inside
+// the statement (cdna_hip_programming.md 5.7); the compiler does not count these operations: every wait is explicit.
+__device__ __forceinline__ void dma16(const void* g, uint32_t lds_off) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");      // wave-uniform by construction
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+constexpr int K1S_D = 4;                          // ring slots per wave; a slot = 2 K16 steps = 4 instructions = 32 rows x 128 B
+constexpr int K1S_RING = K1S_D * 4 * 1024;        // 16 KB per wave
+constexpr int K1S_MAX_KCHUNK = 8192;              // LDS: 64 KB of rings + 8 B per K row of activation bits
+
+struct K1sArgs {
+    const float* W; int64_t ldw; int K, N;        // W[K][ldw] fp32, N valid columns (K = visible, N = hidden units)
+    const uint8_t* abits; int Bp;                 // activations: byte-major bit plane [rup(K,64)/8][Bp]
+    const int* aflag; int ncb, P;                 // exactness map of caller data ([P][ncb], FLAG_NONBINARY): nullptr = binary by construction
+    float* slabs;                                 // [Bp/64][ks][tiles][64][32] partial sums
+    int* counters;                                // [Bp/64][tiles] arrival counters, zero at launch, zero again at exit
+    int kchunk, ks;                               // rows per K slice (multiple of 64), number of slices
+};
+
+template <int NW>
+__global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const FinishArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 rings][activation bits][1 int]; no static LDS (keeps the base 16-B aligned)
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 31, kg = l >> 5;      // w: provably wave-uniform (scalar branches)
+    const int tile = blockIdx.x, sl = blockIdx.y, z = blockIdx.z, ntiles = gridDim.x;
+    const int n0 = tile * 32, mb = z * 64;
+    const int k0 = sl * a.kchunk;
+    const int k_end = min(k0 + a.kchunk, (a.K + 15) / 16 * 16);
+    const int nsteps = (k_end - k0) / 16;                 // K16 steps of this slice; wave w takes steps w, w + 4, ...
+    const int my_steps = (nsteps - w + 3) / 4;
+    const int n_slots = (my_steps + 1) / 2;
+    char* ring = smem + w * K1S_RING;
+    const uint8_t* abl = reinterpret_cast<const uint8_t*>(smem + 4 * K1S_RING);      // [kchunk/8][64] bytes
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)ring);
+    const uint32_t abl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem) + 4 * K1S_RING;
+
+    // ---- activation bits of the slice -> LDS (16 byte-rows = 1 KB per instruction, dealt to the four waves)
+    {
+        const int nrows8 = a.kchunk / 8, last_row = (a.K + 63) / 64 * 8 - 1;
+        for (int q = w; q * 16 < nrows8; q += 4) {
+            const int br = min((k0 >> 3) + 16 * q + (l >> 2), last_row);
+            dma16(a.abits + (int64_t)br * a.Bp + mb + 16 * (l & 3), abl_lds + q * 1024);
+        }
+    }
+    // ---- weight ring
+    const int colc = min(n0 + 4 * (l & 7), a.N - 4);      // 16-B chunk of the 128-B row segment (N % 4 == 0); clamped chunks feed columns >= N only
+    const float* wsrc = a.W + colc;
+    auto issue_slot = [&](int d, int si) {                // ring slot d <- the wave's steps 2 si, 2 si + 1
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int i = 2 * si + sub;
+            if (i < my_steps) {                           // wave-uniform
+                const int krow = k0 + 16 * (4 * i + w) + (l >> 3);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    dma16(wsrc + (int64_t)min(krow + 8 * h, a.K - 1) * a.ldw, ring_lds + ((d * 2 + sub) * 2 + h) * 1024);
+            }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < K1S_D; ++d) issue_slot(d, d);
+    // the bits (issued first) have landed once at most the ring's instructions are outstanding
+    if (my_steps >= 2 * K1S_D) wait_vmcnt<4 * K1S_D>(); else wait_vmcnt<0>();
+    __syncthreads();
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    auto compute = [&](int d, int sub, int i) {           // K16 step i of this wave, in ring slot d
+        const char* base = ring + ((d * 2 + sub) * 2) * 1024 + (8 * kg) * 128 + 4 * n;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(base + j * 128);
+        uint4 bf[NW];
+        make_w_frags<NW>(x, bf);
+        const int jstep = 4 * i + w;                      // K16 step inside the slice: bytes 2 jstep, 2 jstep + 1 of a batch row
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const uint4 af = bits_to_frag(abl[(2 * jstep + kg) * 64 + 32 * mt + n]);
+#pragma unroll
+            for (int tw = 0; tw < NW; ++tw)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af), as_frag(bf[tw]), acc[mt], 0, 0, 0);
+        }
+    };
+    for (int s0 = 0; s0 < n_slots; s0 += K1S_D) {
+#pragma unroll
+        for (int d = 0; d < K1S_D; ++d) {
+            const int si = s0 + d;
+            if (si < n_slots) {                           // wave-uniform
+                // slot si has landed when only the K1S_D - 1 younger slots are outstanding -- if they were all issued in full
+                if (2 * (si + K1S_D - 1) + 1 < my_steps) wait_vmcnt<4 * (K1S_D - 1)>(); else wait_vmcnt<0>();
+                compute(d, 0, 2 * si);
+                if (2 * si + 1 < my_steps) compute(d, 1, 2 * si + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's fragments are in registers: refill it
+                issue_slot(d, si + K1S_D);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();                                      // every wave is done with its ring: the area becomes red[4][64][32]
+
+    // ---- cross-wave sum (fixed order) -> this thread's 8 values: column n0 + c, batch rows mb + 8 oct .. + 7
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) red[(w * 64 + mt * 32 + mfma_row(reg, l)) * 32 + n] = acc[mt][reg];
+    __syncthreads();
+    const int c = tid & 31, oct = tid >> 5;
+    float xs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int o = (8 * oct + i) * 32 + c;
+        xs[i] = ((red[o] + red[2048 + o]) + red[2 * 2048 + o]) + red[3 * 2048 + o];
+    }
+    // caller data that were promised to be 0/1 and are not: the bit plane does not describe them -> NaN, loudly
+    if (a.aflag) {
+        int bad = 0;
+        const int cb0 = k0 / 64, cb1 = min((k_end + 63) / 64, a.ncb), wd = cb1 - cb0;
+        for (int i = tid; i < wd * 8; i += 256) bad |= a.aflag[(z * 8 + i / wd) * a.ncb + cb0 + (i % wd)] & FLAG_NONBINARY;
+        if (__syncthreads_or(bad)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xs[i] = __uint_as_float(0x7FC00000u);
+        }
+    }
+    if (a.ks > 1) {
+        // ---- publish the partial tile (write-through stores, every 128-B line whole from one instruction), count the
+        // arrival; the block whose add comes last sums all slices in slice order (same result whoever is last)
+        typedef __attribute__((address_space(1))) uint32_t gu32;
+        gu32* mine = (gu32*)(a.slabs + (((int64_t)z * a.ks + sl) * ntiles + tile) * 2048);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __hip_atomic_store(mine + (8 * oct + i) * 32 + c, __float_as_uint(xs[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the barrier, the counter add comes after it
+        __syncthreads();
+        int* cnt = a.counters + z * ntiles + tile;
+        int* s_last = reinterpret_cast<int*>(smem + 4 * K1S_RING + 8 * a.kchunk);
+        if (tid == 0) *s_last = (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ks - 1) ? 1 : 0;
+        __syncthreads();
+        if (!*s_last) return;
+        if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xs[i] = 0.f;
+        const gu32* s0p = (const gu32*)(a.slabs + ((int64_t)z * a.ks * ntiles + tile) * 2048) + (8 * oct) * 32 + c;
+        int k = 0;
+        for (; k + 4 <= a.ks; k += 4) {                   // 32 loads in flight; summed strictly in slice order
+            uint32_t t[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[q][i] = __hip_atomic_load(s0p + (int64_t)(k + q) * ntiles * 2048 + i * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xs[i] = (k + q == 0) ? __uint_as_float(t[q][i]) : xs[i] + __uint_as_float(t[q][i]);
+        }
+        for (; k < a.ks; ++k) {
+            uint32_t t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = __hip_atomic_load(s0p + (int64_t)k * ntiles * 2048 + i * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xs[i] = (k == 0) ? __uint_as_float(t[i]) : xs[i] + __uint_as_float(t[i]);
+        }
+    }
+    // ---- epilogue of `finish`, fused: bias, sigmoid, Bernoulli sample, operand forms, column sums
+    const int ecol = (n0 + c < a.N) ? n0 + c : (1 << 30);
+    SideIn<8> side;
+    load_side<8>(fa, ecol, mb + 8 * oct, side);
+    (void)finish_rows8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, side, nullptr);
+}
+
+}  // namespace imdbn

@@ -62,7 +62,7 @@ class UniformDataset(Dataset):
         img = img.reshape(img.shape[0], -1)
         if img.dtype != np.uint8:
             mx = float(img.max()) if img.size else 0.0
-            img = (img > 0.5 * mx).astype(np.uint8) if mx > 1.0 else np.rint(np.clip(img, 0, 1) * 255).astype(np.uint8)
+            img = (img > 0.5 * mx).astype(np.uint8) * np.uint8(255) if mx > 1.0 else np.rint(np.clip(img, 0, 1) * 255).astype(np.uint8)
         elif img.size and img.max() <= 1:
             img = img * np.uint8(255)
         self.images_u8 = torch.from_numpy(np.ascontiguousarray(img))            # [N, P], 0..255 (255 = 1.0)
@@ -122,6 +122,9 @@ class DeviceLoader:
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(int(seed))
         self.epoch = 0
+        # binary stimuli (every pixel 0 or 255): the batches carry the tag the engine reads instead of checking each one
+        # (HipEngine.data_is_binary): their CD updates read the images as bit planes
+        self._binary = bool(((self._x == 0) | (self._x == 255)).all().item()) if self._x.numel() else False
 
     def _global(self) -> int:
         return self.batch_size * self.world_size
@@ -145,6 +148,7 @@ class DeviceLoader:
                 sel = order[lo:hi]
                 x, k = self._x.index_select(0, sel), self._k.index_select(0, sel)
             xf = x.to(torch.float32).mul_(1.0 / 255.0)
+            xf._imdbn_binary = self._binary
             yield xf, (torch.nn.functional.one_hot(k, self._K).to(torch.float32) if self._onehot else k)
 
 

@@ -8,6 +8,7 @@ scratch workspaces keyed on (device, V, H, B).
 from __future__ import annotations
 
 import os
+import weakref
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -40,6 +41,10 @@ class HipEngine:
         self._pf: Dict[tuple, tuple] = {}           # workspace key -> (identity of the prefetched batch, slot, tensor)
         self._pf_ok: Dict[tuple, bool] = {}
         self.mode = N.PARITY_F32
+        # "is this batch 0/1?" (imdbn_cd_opts.data_binary): answers cached per live tensor object
+        self._bin: Dict[int, tuple] = {}
+        self._bin_misses = 0
+        self.binary_check = os.environ.get("IMDBN_BINARY_CHECK", "auto")      # "auto" | "never"
         # tuning / A-B aid: IMDBN_OPTS="name=value,..." -> imdbn_set_option (include/imdbn_engine.h)
         for kv in filter(None, os.environ.get("IMDBN_OPTS", "").split(",")):
             k, _, v = kv.partition("=")
@@ -238,6 +243,33 @@ class HipEngine:
         o.sample_h, o.sample_v, o.reclamp_negative = int(bool(sample_h)), int(bool(sample_v)), int(bool(reclamp))
         return o
 
+    def data_is_binary(self, x: torch.Tensor) -> bool:
+        """True when every element of the batch `x` is known to be exactly 0 or 1: the positive phase of the CD update then
+        reads it as a bit plane (the device re-checks the claim and turns the update into NaN if it is false).
+
+        Known = the tensor carries the tag ``_imdbn_binary`` (``imdbn.datasets.DeviceLoader`` batches, engine outputs), or
+        this very tensor object (same storage, same version) was checked before.  An unknown tensor is checked once
+        (one device reduction + host sync); after 64 unknown tensors in a row -- a loader that builds a fresh tensor per
+        step -- the engine stops asking and takes the general path.  ``IMDBN_BINARY_CHECK=never`` disables the check."""
+        tag = getattr(x, "_imdbn_binary", None)
+        if tag is not None:
+            return bool(tag)
+        if self.binary_check == "never":
+            return False
+        key = id(x)
+        hit = self._bin.get(key)
+        if hit is not None and hit[0]() is x and hit[1] == (x.data_ptr(), x._version, tuple(x.shape)):
+            self._bin_misses = 0
+            return hit[2]
+        if self._bin_misses >= 64:
+            return False
+        self._bin_misses += 1
+        val = bool(((x == 0) | (x == 1)).all().item())
+        if len(self._bin) > 1024:
+            self._bin = {k: v for k, v in self._bin.items() if v[0]() is not None}
+        self._bin[key] = (weakref.ref(x), (x.data_ptr(), x._version, tuple(x.shape)), val)
+        return val
+
     @staticmethod
     def _ident(t: torch.Tensor):
         """What must be unchanged for prefetched operand forms of `t` to be still valid (best effort: writes through
@@ -251,7 +283,7 @@ class HipEngine:
             ok = self._pf_ok[key] = bool(self._lib.imdbn_rbm_prefetch_ok(C.byref(d), B))
         return ok
 
-    def cd_step(self, rbm, data, lr, mom, cd_k, rng, next_data=None):
+    def cd_step(self, rbm, data, lr, mom, cd_k, rng, next_data=None, data_binary=None):
         """One CD-k update.  ``next_data``: the batch the NEXT cd_step of this shape will get -- its operand forms are
         then prepared by extra blocks of this call's first negative-phase launch and the
         next call skips its own preparation when it is handed that very tensor, unmodified."""
@@ -259,6 +291,7 @@ class HipEngine:
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
         o = self._opts(rbm, lr, mom, cd_k, sparsity=getattr(rbm, "sparsity", False))
+        o.data_binary = int(self.data_is_binary(data) if data_binary is None else bool(data_binary))
         sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
         r, keep = self._rng(rng, sched, B, dev)
         loss = torch.empty(1, device=dev)
@@ -292,11 +325,12 @@ class HipEngine:
             buf = self._ws[key] = torch.zeros(self.packed_floats(W.shape[0], W.shape[1]), device=W.device)
         return buf
 
-    def cd_stats(self, rbm, data, cd_k, rng, out: Optional[torch.Tensor] = None):
+    def cd_stats(self, rbm, data, cd_k, rng, out: Optional[torch.Tensor] = None, data_binary=None):
         d = self._desc(rbm, False)
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
         o = self._opts(rbm, 0.0, 0.0, cd_k)
+        o.data_binary = int(self.data_is_binary(data) if data_binary is None else bool(data_binary))
         sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
         r, keep = self._rng(rng, sched, B, dev)
         n = self.packed_floats(d.V, d.H)
@@ -319,13 +353,14 @@ class HipEngine:
         return (W.is_cuda and 1 <= B <= 64 and W.shape[1] % 4 == 0 and W.stride(0) % 4 == 0 and W.data_ptr() % 16 == 0
                 and not self._groups(rbm))
 
-    def cd_factors(self, rbm, data, cd_k, rng) -> torch.Tensor:
+    def cd_factors(self, rbm, data, cd_k, rng, data_binary=None) -> torch.Tensor:
         """The CD pass of this rank's rows; returns the factor block (a uint8 VIEW of the workspace: consume it --
         e.g. all-gather it -- before the next engine call on this RBM shape)."""
         d = self._desc(rbm, False)
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
         o = self._opts(rbm, 0.0, 0.0, cd_k)
+        o.data_binary = int(self.data_is_binary(data) if data_binary is None else bool(data_binary))
         sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
         r, keep = self._rng(rng, sched, B, dev)
         ws = self._workspace(dev, d.V, d.H, B)

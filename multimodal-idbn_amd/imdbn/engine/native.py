@@ -10,6 +10,7 @@ import ctypes as C
 import os
 
 MAX_GROUPS = 4
+ABI_VERSION = 2
 PARITY_F32, FAST_BF16 = 0, 1
 RNG_PHILOX, RNG_REPLAY = 0, 1
 
@@ -46,7 +47,8 @@ class CdOpts(C.Structure):
     _fields_ = [("cd_k", C.c_int32), ("lr", C.c_float), ("momentum", C.c_float), ("weight_decay", C.c_float),
                 ("sparsity", C.c_int32), ("sparsity_target", C.c_float),
                 ("sample_h", C.c_int32), ("sample_v", C.c_int32), ("reclamp_negative", C.c_int32),
-                ("next_data", C.c_void_p), ("ld_next", C.c_int64), ("next_slot", C.c_int32), ("data_slot", C.c_int32)]
+                ("next_data", C.c_void_p), ("ld_next", C.c_int64), ("next_slot", C.c_int32), ("data_slot", C.c_int32),
+                ("data_binary", C.c_int32)]
 
 
 _P = C.c_void_p

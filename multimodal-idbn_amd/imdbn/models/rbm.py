@@ -79,6 +79,22 @@ class RBM(nn.Module):
         self.hb_m = torch.zeros_like(self.hid_bias)
         self.vb_m = torch.zeros_like(self.vis_bias)
 
+    # ---- pickle state ----------------------------------------------------
+    def __getstate__(self):
+        """The reference's plain attribute state.  On the GPU ``W`` / ``W_m`` are views of row-padded buffers; a pickle
+        must not carry that storage: they are written as contiguous ``[V, H]`` tensors (stride ``(H, 1)``), exactly what
+        the reference class -- or this one -- expects to unpickle."""
+        state = self.__dict__.copy()
+        params = state["_parameters"].copy()
+        W = params.get("W")
+        if W is not None and not W.is_contiguous():
+            params["W"] = nn.Parameter(W.data.contiguous(), requires_grad=W.requires_grad)
+        state["_parameters"] = params
+        Wm = state.get("W_m")
+        if isinstance(Wm, torch.Tensor) and not Wm.is_contiguous():
+            state["W_m"] = Wm.contiguous()
+        return state
+
     # ---- helpers ------------------------------------------------------------------------------
     def _eng(self):
         return _E.get_engine(self.W.data)
@@ -101,7 +117,9 @@ class RBM(nn.Module):
     @torch.no_grad()
     def forward(self, v: torch.Tensor, T: float = 1.0) -> torch.Tensor:
         """p(h|v) = sigmoid((v W + c)/max(1e-6,T))   (rbm.py:92)."""
-        return self._eng().prop_up(self, self._in(v), T=T)
+        out = self._eng().prop_up(self, self._in(v), T=T)
+        out._imdbn_binary = False      # probabilities: the next layer's update need not ask (HipEngine.data_is_binary)
+        return out
 
     @torch.no_grad()
     def _visible_logits(self, h: torch.Tensor, T: float = 1.0) -> torch.Tensor:
@@ -171,12 +189,15 @@ class RBM(nn.Module):
         lr, mom = self._lr_mom(epoch)
         eng, x = self._eng(), self._in(data)
         rng = self._rng(x.size(0))
+        # 0/1 batches (binary images) are read as bit planes by the positive phase; asked of the caller's tensor object,
+        # which may carry the loader's tag (``_in`` makes a fresh view every call)
+        kw = {"data_binary": eng.data_is_binary(data)} if hasattr(eng, "data_is_binary") else {}
         dp = _E.dp
         if dp.active():
             B = x.size(0)
             if dp.mode() == "factors" and hasattr(eng, "factor_mode_ok") and eng.factor_mode_ok(self, B):
                 # exchange the factors (~7 MB per rank at 10000 x 1500) instead of the fp32 statistics (60 MB)
-                block = eng.cd_factors(self, x, CD, rng)
+                block = eng.cd_factors(self, x, CD, rng, **kw)
                 if hasattr(eng, "pack_factors"):
                     # wire form: the visible planes as bits (the sample always, the data when declared binary)
                     binary = dp.binary_data()
@@ -190,12 +211,12 @@ class RBM(nn.Module):
                     gathered = dp.all_gather_blocks(eng.gather_buffer(self, B, dp.world_size()), block)
                 return eng.apply_factors(self, gathered, B, B * dp.world_size(), lr, mom)
             buf = eng.packed_buffer(self) if hasattr(eng, "packed_buffer") else None
-            packed = eng.cd_stats(self, x, CD, rng, out=buf)
+            packed = eng.cd_stats(self, x, CD, rng, out=buf, **kw)
             dp.all_reduce_sum(packed)
             return eng.apply_delta(self, packed, B * dp.world_size(), lr, mom)
         if next_data is not None:
-            return eng.cd_step(self, x, lr, mom, CD, rng, next_data=next_data)
-        return eng.cd_step(self, x, lr, mom, CD, rng)
+            return eng.cd_step(self, x, lr, mom, CD, rng, next_data=next_data, **kw)
+        return eng.cd_step(self, x, lr, mom, CD, rng, **kw)
 
     # ---- schedules (rbm.py:229-238) -------------------------------------------------------------
     def _lin_schedule(self, t, t_max, start, end):

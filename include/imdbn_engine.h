@@ -141,6 +141,9 @@ int    imdbn_profile_read(double* total_ms, int* launches);   /* synchronises th
 /* tuning aid: copies the per-block wall-clock stamps (100 MHz ticks, 8 per block, up to 4096 blocks) that the
  * propagation kernels record when the "dbg" option enables them; synchronises the device */
 int    imdbn_debug_stamps(long long* out, int n);
+/* test / tuning aid: byte offset of a named internal buffer inside the workspace of an (V, H, B) call ("vis_bits0/1", "hid_bits",
+ * "vis_tr0/1", "hid_tr0/1", "cs_hpos/hneg/vpos/vneg", "flags", "partial", "vis_rm1"); the layout is NOT part of the ABI */
+int    imdbn_debug_ws_offset(int V, int H, int B, const char* name, size_t* offset);
 
 /* ---- K1: p(h|v)   replaces RBM.forward (rbm.py:81-92) ---------------------------------- */
 /* out_prob[B][H] = sigmoid((v W + c)/T);  out_sample (nullable) = 1[out_prob > U] */

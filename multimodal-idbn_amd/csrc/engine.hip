@@ -837,6 +837,23 @@ int imdbn_debug_stamps(long long* out, int n) {
     return 0;
 }
 
+int imdbn_debug_ws_offset(int V, int H, int B, const char* name, size_t* offset) {
+    if (V <= 0 || H <= 0 || B <= 0 || !name || !offset) return fail(IMDBN_E_INVALID, "debug_ws_offset: bad argument");
+    char* fake = reinterpret_cast<char*>((uintptr_t)1 << 30);
+    const Layout L = make_layout(V, H, B, fake);
+    const void* p = nullptr;
+    if (!strcmp(name, "vis_bits0")) p = L.vis_bits[0]; else if (!strcmp(name, "vis_bits1")) p = L.vis_bits[1];
+    else if (!strcmp(name, "hid_bits")) p = L.hid_bits; else if (!strcmp(name, "vis_tr0")) p = L.vis_tr[0];
+    else if (!strcmp(name, "vis_tr1")) p = L.vis_tr[1]; else if (!strcmp(name, "hid_tr0")) p = L.hid_tr[0];
+    else if (!strcmp(name, "hid_tr1")) p = L.hid_tr[1]; else if (!strcmp(name, "cs_hpos")) p = L.cs_hpos;
+    else if (!strcmp(name, "cs_hneg")) p = L.cs_hneg; else if (!strcmp(name, "cs_vpos")) p = L.cs_vpos;
+    else if (!strcmp(name, "cs_vneg")) p = L.cs_vneg; else if (!strcmp(name, "flags")) p = L.flags;
+    else if (!strcmp(name, "partial")) p = L.partial; else if (!strcmp(name, "vis_rm1")) p = L.vis_rm[1];
+    else return fail(IMDBN_E_INVALID, "debug_ws_offset: unknown buffer %s", name);
+    *offset = (size_t)((const char*)p - fake);
+    return 0;
+}
+
 int imdbn_profile_read(double* total_ms, int* launches) {
     double tot = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {

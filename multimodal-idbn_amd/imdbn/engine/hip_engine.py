@@ -73,6 +73,13 @@ class HipEngine:
         N.check(self._lib.imdbn_profile_read(C.byref(ms), C.byref(n)), "imdbn_profile_read")
         return ms.value, n.value
 
+    def debug_buffer(self, dev, V, H, B, name: str, nbytes: int) -> torch.Tensor:
+        """Test aid: uint8 view of a named internal buffer of the (V, H, B) workspace (imdbn_debug_ws_offset)."""
+        off = C.c_size_t(0)
+        N.check(self._lib.imdbn_debug_ws_offset(int(V), int(H), int(B), name.encode(), C.byref(off)), "imdbn_debug_ws_offset")
+        ws = self._workspace(torch.device(dev), V, H, B)
+        return ws[off.value:off.value + nbytes]
+
     def _workspace(self, dev, V, H, B):
         key = (dev, V, H, B)
         ws = self._ws.get(key)

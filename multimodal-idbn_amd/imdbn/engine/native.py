@@ -68,6 +68,7 @@ SIGNATURES = {
     "imdbn_profile_enable": (_INT, [_INT]),
     "imdbn_profile_read": (_INT, [C.POINTER(C.c_double), C.POINTER(_INT)]),
     "imdbn_debug_stamps": (_INT, [C.POINTER(C.c_longlong), _INT]),
+    "imdbn_debug_ws_offset": (_INT, [_INT, _INT, _INT, C.c_char_p, C.POINTER(_SZ)]),
     "imdbn_rbm_prop_up": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _F, C.POINTER(Rng), _P, _I64, _P, _I64, _P, _SZ, _P]),
     "imdbn_rbm_free_energy": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _P, _P, _SZ, _P]),
     "imdbn_rbm_prop_down": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _F, _INT, _P, _I64, _P, _SZ, _P]),

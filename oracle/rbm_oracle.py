@@ -33,11 +33,35 @@ def reset_margin():
     BERNOULLI_MARGIN["min"] = float("inf")
 
 
+# Near ties: 1[p > u] is discontinuous, and at full size (~10^6 comparisons per update) some |p - u| are
+# at fp32 rounding level, where the summation order of the propagation decides.  A test that holds the samples the
+# accelerator actually drew can queue them here (one array per Bernoulli tensor, in draw order; None = no override):
+# wherever |p - u| < tol the queued decision is taken instead of this restatement's own.  `used` counts how many
+# decisions that changed, `ties` how many elements were within tol -- the caller asserts that both stay tiny.
+TIE_BREAK = {"tol": 0.0, "queue": [], "used": 0, "ties": 0}
+
+
+def set_tie_break(decisions=None, tol: float = 2e-6):
+    TIE_BREAK["tol"] = float(tol)
+    TIE_BREAK["queue"] = list(decisions or [])
+    TIE_BREAK["used"] = 0
+    TIE_BREAK["ties"] = 0
+
+
 def _bern(p, u):
     """1[p > u] as float32, tracking the smallest margin."""
     if p.size:
         BERNOULLI_MARGIN["min"] = min(BERNOULLI_MARGIN["min"], float(np.abs(p - u).min()))
-    return (p > u).astype(F32)
+    out = p > u
+    if TIE_BREAK["queue"]:
+        d = TIE_BREAK["queue"].pop(0)
+        if d is not None:
+            tie = np.abs(p - u) < F32(TIE_BREAK["tol"])
+            d = np.asarray(d).astype(bool).reshape(out.shape)
+            TIE_BREAK["ties"] += int(tie.sum())
+            TIE_BREAK["used"] += int((tie & (out != d)).sum())
+            out = np.where(tie, d, out)
+    return out.astype(F32)
 
 
 

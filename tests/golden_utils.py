@@ -56,3 +56,15 @@ def assert_close(got, want, rel=1e-5, what="", atol=0.0):
             f"(got {got[worst] if diff.ndim else got}, want {want[worst] if diff.ndim else want}); "
             f"{int((diff > 10 * max(atol, 1e-6)).sum())} elements differ by >1e-5 -- a handful of rows/cols "
             f"differing at ~lr/B scale means a Bernoulli unit flipped (SURVEY 7.3-a)")
+
+
+def gpu_cd_samples(eng, dev, V, H, B):
+    """The Bernoulli samples of the LAST CD-1 update the engine ran on the (V, H, B) workspace, read from its operand buffers
+    (test aid imdbn_debug_ws_offset): (h0 [B, H], v' [B, V]) as bool arrays -- what oracle.rbm_oracle.set_tie_break takes."""
+    import torch
+    torch.cuda.synchronize()
+    Bp, H64 = (B + 63) // 64 * 64, (H + 63) // 64 * 64
+    hb = eng.debug_buffer(dev, V, H, B, "hid_bits", H64 // 8 * Bp).cpu().numpy().reshape(H64 // 8, Bp)
+    h = np.unpackbits(hb[:, :, None], axis=2, bitorder="little").transpose(0, 2, 1).reshape(H64, Bp)[:H, :B].T.astype(bool)
+    plane = eng.debug_buffer(dev, V, H, B, "vis_tr1", V * Bp * 2).cpu().numpy().view(np.uint16).reshape(V, Bp)
+    return h, (plane[:, :B] != 0).T

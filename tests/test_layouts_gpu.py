@@ -14,7 +14,7 @@ import torch
 
 import oracle.rbm_oracle as O
 import parity_cases as P
-from golden_utils import Fixture, assert_close, init_W, rel_fro
+from golden_utils import Fixture, assert_close, gpu_cd_samples, init_W, rel_fro
 from oracle.draws import DrawStream, PhiloxStream
 
 pytestmark = pytest.mark.gpu
@@ -95,17 +95,23 @@ def test_headline_rbm_as_constructed_with_poisoned_padding(pitch_env, want_pitch
     Xa = (g.random((B, Vv), dtype=F32) > 0.9).astype(F32)
     Xb = (g.random((B, Vv), dtype=F32) > 0.9).astype(F32)
     ta, tb = P.T(Xa, DEV), P.T(Xb, DEV)
-    with E.use_rng(E.PhiloxRng(seed=21)):
-        l1 = r.train_epoch(ta, 0, 10, CD=1, next_data=tb)
-        l2 = r.train_epoch(tb, 0, 10, CD=1)
-    _padding_untouched(r)
+    eng = E.get_hip_engine()
     st = O.RBMState.create(Wn, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95)
     ps = PhiloxStream(21)
-    o1 = O.train_epoch(st, Xa, 0, 1, ps)
-    o2 = O.train_epoch(st, Xb, 0, 1, ps)
-    assert_close(np.array([float(l1), float(l2)], F32), np.array([o1, o2], F32), 1e-5, "losses")
-    for k in P.KEYS:
-        assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
+    with E.use_rng(E.PhiloxRng(seed=21)):
+        # ~830 000 Bernoulli comparisons per update: a few |p - u| are at fp32 rounding level, where the summation order decides
+        # (SURVEY 7.3-a).  The oracle takes the sample the device drew wherever its own margin is < 2e-6 and reports how often.
+        for x, t, nxt in ((Xa, ta, tb), (Xb, tb, None)):
+            l = r.train_epoch(t, 0, 10, CD=1, next_data=nxt)
+            h_gpu, v_gpu = gpu_cd_samples(eng, DEV, Vv, Hh, B)
+            O.set_tie_break([h_gpu, v_gpu, None], tol=2e-6)
+            o = O.train_epoch(st, x, 0, 1, ps)
+            assert O.TIE_BREAK["ties"] < 60 and O.TIE_BREAK["used"] <= 6, dict(O.TIE_BREAK, queue=None)
+            O.set_tie_break(None)
+            assert_close(float(l), o, 1e-5, "loss")
+            for k in P.KEYS:
+                assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
+    _padding_untouched(r)
 
 
 def test_gpu_pickle_of_a_padded_rbm_is_contiguous(tmp_path):
@@ -176,11 +182,15 @@ def test_config4_eight_ranks_of_64_rows_full_size(_native):
     xs = [P.T(X[rk * Bl:(rk + 1) * Bl], DEV) for rk in range(R)]
     with E.use_rng(E.PhiloxRng(seed=77)):
         l1 = r1.train_epoch(P.T(X, DEV), 0, 1, CD=1)                          # one rank, eight 64-row chunks
+    dec1 = gpu_cd_samples(eng, DEV, V, H, B)
     assert eng.factor_mode_ok(r2, Bl)
     wires = eng.compact_gather_buffer(r2, Bl, R, True)
+    dec2 = []
     for rk in range(R):
         blk = eng.cd_factors(r2, xs[rk], 1, E.PhiloxRng(seed=77, row0=rk * Bl))
+        dec2.append(gpu_cd_samples(eng, DEV, V, H, Bl))
         wires[rk].copy_(eng.pack_factors(r2, blk, Bl, True))
+    dec2 = (np.concatenate([d[0] for d in dec2]), np.concatenate([d[1] for d in dec2]))
     planes = eng.unpack_factors(r2, wires, Bl, True, planes_only=True)
     l2 = eng.apply_factors_wire(r2, wires, planes, Bl, B, lr, mom)
     packed = None
@@ -190,15 +200,25 @@ def test_config4_eight_ranks_of_64_rows_full_size(_native):
     l3 = eng.apply_delta(r3, packed, B, lr, mom)
     for r in (r1, r2, r3):
         _padding_untouched(r)
-    assert_close(np.array([float(l2), float(l3)], F32), np.array([float(l1)] * 2, F32), 1e-5, "losses")
+    # both exchanges run the same per-rank kernels: identical samples, identical update
+    assert_close(float(l3), float(l2), 1e-6, "loss: all-reduce vs factor exchange")
     for k in P.KEYS:
-        assert_close(P.N(getattr(r2, k)), P.N(getattr(r1, k)), 1e-5, "factors vs single process: " + k, atol=2e-6)
-        assert_close(P.N(getattr(r3, k)), P.N(getattr(r1, k)), 1e-5, "all-reduce vs single process: " + k, atol=2e-6)
-    st = O.RBMState.create(W0, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95)
-    o = O.train_epoch(st, X, 0, 1, PhiloxStream(77))
-    assert_close(float(l1), o, 1e-5, "loss vs oracle")
-    for k in P.KEYS:
-        assert_close(P.N(getattr(r1, k)), getattr(st, k), 1e-4, "single process vs oracle: " + k, atol=2e-6)
+        assert_close(P.N(getattr(r3, k)), P.N(getattr(r2, k)), 1e-5, "all-reduce vs factors: " + k, atol=2e-6)
+    # 6.6 million Bernoulli comparisons: the 8-chunk launch and the 64-row launches split K differently, so a handful of
+    # near-tie samples (|p - u| < 2e-6) may differ between them; each is checked against the oracle with ITS samples at the ties
+    same = all(np.array_equal(a, b) for a, b in zip(dec1, dec2))
+    if same:
+        for k in P.KEYS:
+            assert_close(P.N(getattr(r2, k)), P.N(getattr(r1, k)), 1e-5, "factors vs single process: " + k, atol=2e-6)
+    for name, rr, ll, dec in (("single process", r1, l1, dec1), ("8 ranks", r2, l2, dec2)):
+        st = O.RBMState.create(W0, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95)
+        O.set_tie_break([dec[0], dec[1], None], tol=2e-6)
+        o = O.train_epoch(st, X, 0, 1, PhiloxStream(77))
+        assert O.TIE_BREAK["ties"] < 300 and O.TIE_BREAK["used"] <= 30, dict(O.TIE_BREAK, queue=None)
+        O.set_tie_break(None)
+        assert_close(float(ll), o, 1e-5, name + ": loss vs oracle")
+        for k in P.KEYS:
+            assert_close(P.N(getattr(rr, k)), getattr(st, k), 1e-4, name + " vs oracle: " + k, atol=2e-6)
 
 
 @pytest.mark.parametrize("live_k", [None, 16])

@@ -380,7 +380,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         a.abits = in.bits; a.Bp = L.Bp;
         a.aflag = in.binary == 2 ? in.flag : nullptr; a.ncb = cdiv(L.Vpad, 64); a.P = L.P;
         a.slabs = L.partial; a.counters = L.k1s_cnt; a.kchunk = L.k1s_kchunk; a.ks = L.k1s_ks;
-        f.dbg = 0;
+        f.dbg = g_dbg;
         f.op.bits = want_hbits ? L.hid_bits : nullptr; f.op.bits_shape = 1; f.op.bits_cols = 32;
         if (f.op.rm == L.hid_rm) c.hid_bits_ok = want_hbits;
         if (want_hbits && !g_no_bits) f.op.rm = nullptr, f.rm_src = 0;      // the fused K2 reads the bit plane, nobody reads the bf16 form
@@ -580,6 +580,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
     if (!c.data_prepped) CHK(prep(c, data, ldd, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], L.flags, L.cs_vpos, 3, L.vis_bits[0]));
     // the visible sample of the negative phase leaves the fused K2 as a bit plane too when its tiles are whole bytes wide
     const bool vbits = c.d->n_groups == 0 && L.down_tr % 8 == 0;
+    const bool k1s_neg = vec4_weights(c.d) && !g_no_k1s && L.Vpad > 1024;      // the negative-phase K1 will be k1_stream (prop())
     // positive phase: P+ = up(data); h = 1[P+ > U]
     {
         FinishArgs f = new_finish();
@@ -597,7 +598,9 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
             c.rng.cats(B, c.d->n_groups, &f.cat_tape, &f.cat_uni);
             // the fp32 copies of v_prob / v are only read back by the softmax-group kernel (prop() supplies
             // scratch for them when groups exist): without groups nobody needs them -> 5 MB of stores saved
-            f.op.rm = L.vis_rm[1]; f.op.rm_terms = 1; f.rm_src = 2;
+            // the K16-blocked bf16 form only feeds a K1 that cannot read the bit plane (its 2-byte scattered stores were most
+            // of the fused K2's 3.8 us epilogue)
+            if (!(vbits && k1s_neg)) { f.op.rm = L.vis_rm[1]; f.op.rm_terms = 1; f.rm_src = 2; }
             f.op.tr = L.vis_tr[1]; f.op.tr_terms = 1; f.tr_src = 2;
             f.colsum_part = L.cs_vneg; f.colsum_src = 2;
             f.loss_ref = data; f.ld_ref = ldd; f.loss_src = 1; f.loss_part = L.loss_part;

@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)ring);
     const uint32_t abl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem) + 4 * K1S_RING;
 
+    const bool st = (fa.dbg & 64) != 0;                   // tuning aid: per-block timeline (tools/stamps_probe.py)
+    const int sblk = (z * gridDim.y + sl) * ntiles + tile;
+    stamp(st, sblk, 0);
     // ---- activation bits of the slice -> LDS (16 byte-rows = 1 KB per instruction, dealt to the four waves)
     {
         const int nrows8 = a.kchunk / 8, last_row = (a.K + 63) / 64 * 8 - 1;
@@ -78,11 +81,18 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             }
         }
     };
+    // epilogue side inputs (bias, ...) of this thread's column x 8 rows: requested now (before the ring, so that the counted
+    // waits below still see the ring's instructions as the youngest), used by the tile's last arriver -- their first-touch
+    // latency would otherwise sit behind the split-K combine
+    const int ecol = (n0 + (tid & 31) < a.N) ? n0 + (tid & 31) : (1 << 30);
+    SideIn<8> side;
+    load_side<8>(fa, ecol, mb + 8 * (tid >> 5), side);
 #pragma unroll
     for (int d = 0; d < K1S_D; ++d) issue_slot(d, d);
     // the bits (issued first) have landed once at most the ring's instructions are outstanding
     if (my_steps >= 2 * K1S_D) wait_vmcnt<4 * K1S_D>(); else wait_vmcnt<0>();
     __syncthreads();
+    stamp(st, sblk, 1);
 
     f32x16 acc[2];
 #pragma unroll
@@ -121,6 +131,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
         }
     }
     wait_vmcnt<0>();
+    stamp(st, sblk, 2);
     __syncthreads();                                      // every wave is done with its ring: the area becomes red[4][64][32]
 
     // ---- cross-wave sum (fixed order) -> this thread's 8 values: column n0 + c, batch rows mb + 8 oct .. + 7
@@ -147,6 +158,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             for (int i = 0; i < 8; ++i) xs[i] = __uint_as_float(0x7FC00000u);
         }
     }
+    stamp(st, sblk, 3);
     if (a.ks > 1) {
         // ---- publish the partial tile (write-through stores, every 128-B line whole from one instruction), count the
         // arrival; the block whose add comes last sums all slices in slice order (same result whoever is last)
@@ -160,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
         int* s_last = reinterpret_cast<int*>(smem + 4 * K1S_RING + 8 * a.kchunk);
         if (tid == 0) *s_last = (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ks - 1) ? 1 : 0;
         __syncthreads();
+        stamp(st, sblk, 4);
         if (!*s_last) return;
         if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
 #pragma unroll
@@ -185,11 +198,10 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             for (int i = 0; i < 8; ++i) xs[i] = (k == 0) ? __uint_as_float(t[i]) : xs[i] + __uint_as_float(t[i]);
         }
     }
+    stamp(st, sblk, 5);
     // ---- epilogue of `finish`, fused: bias, sigmoid, Bernoulli sample, operand forms, column sums
-    const int ecol = (n0 + c < a.N) ? n0 + c : (1 << 30);
-    SideIn<8> side;
-    load_side<8>(fa, ecol, mb + 8 * oct, side);
     (void)finish_rows8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, side, nullptr);
+    stamp(st, sblk, 6);
 }
 
 }  // namespace imdbn

@@ -17,7 +17,7 @@ eng = E.get_hip_engine()
 rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
 x = (torch.rand(B, V) > 0.9).float().to(dev)
 E.set_rng(E.PhiloxRng(seed=2))
-for which, bit, nslots in (("K1 up4 (last launch = negative phase)", 64, 5), ("K2 down_fused", 128, 8),
+for which, bit, nslots in (("K1 k1_stream (last launch = negative phase): start, bits+ring landed, loop done, reduced, published, [last arriver:] combined, epilogue done", 64, 7), ("K2 down_fused", 128, 8),
                            ("K2 down_fused, no operand stores", 128 + 1024, 7), ("K2 down_fused, no sigmoid", 128 + 2048, 7),
                            ("K2 down_fused, neither", 128 + 1024 + 2048, 7),
                            ("finish (last launch = hidden, negative phase)", 256, 4), ("K3 assoc_update_planes", 512, 6)):
@@ -29,6 +29,12 @@ for which, bit, nslots in (("K1 up4 (last launch = negative phase)", 64, 5), ("K
     native.check(native.lib().imdbn_debug_stamps(buf, 4096 * 8), "imdbn_debug_stamps")
     a = np.frombuffer(buf, dtype=np.int64).reshape(4096, 8).copy()
     nb = int((a[:, 0] > 0).sum())
+    if bit == 64:      # k1_stream: only the last arriver of a tile has slots 5, 6
+        last = a[:nb][a[:nb, 6] > 0]
+        b = last[:, :7].astype(np.float64) / 100.0
+        b -= a[:nb, 0].min() / 100.0
+        print(f"== k1_stream last arrivers ({len(b)} blocks): p50 " + " ".join(f"{np.percentile(b[:, j], 50):7.2f}" for j in range(7)) + " | max " + " ".join(f"{b[:, j].max():7.2f}" for j in range(7)))
+        nslots = 5
     a = a[:nb, :nslots].astype(np.float64) / 100.0     # us
     t0 = a[:, 0].min()
     a -= t0

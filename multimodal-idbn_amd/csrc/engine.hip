@@ -38,6 +38,8 @@ int g_no_bits = 0;  // testing: never use the bit-packed hidden operand
 int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
 int g_no_k1s = 0;  // testing: never use the LDS-DMA streaming K1 for binary operands (k1_stream)
 int g_k1s_ks = 0;  // tuning: K slices of k1_stream (0 = automatic)
+int g_no_k2s = 0;  // testing: never use k2_stream (the fused K2 for a bit-plane hidden operand, one tile per CU)
+int g_k2s_tr = 0;  // tuning: rows per k2_stream block (0 = automatic; multiple of 8, <= 48)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
@@ -110,6 +112,7 @@ struct Layout {
     ChainRec* chain_recs;   // per-step schedule of the row-parallel chain kernel
     bf16_t* k4_planes; int64_t k4_plane_stride;      // fragment-ordered bf16 weight planes [2 directions][3 terms]
     int down_tr;            // visible rows per block of the fused K2 (<= 32): balances the row tiles over the CUs
+    int k2s_tr;             // rows per k2_stream block: one tile per CU where the layer is large enough
     int k1s_tiles, k1s_ks, k1s_kchunk; int* k1s_cnt;      // k1_stream: 32-column tiles, K slices, arrival counters [Bp/64][tiles]
     size_t bytes;
 };
@@ -132,7 +135,7 @@ int plan_down_rows(int V) {
     if (g_down_tr > 0) return g_down_tr;
     const int cus = cu_count();
     int best = 32, best_cost = 1 << 30;
-    for (int tr = 32; tr >= 16; tr -= 8) {                  // multiples of 8: the epilogue writes the sample's bit plane byte-wise
+    for (int tr = 32; tr >= 16; tr -= 4) {
         const int cost = cdiv(cdiv(V, tr), cus) * tr;       // rows streamed by the busiest CU
         if (cost < best_cost) { best_cost = cost; best = tr; }
     }
@@ -156,6 +159,7 @@ Layout make_layout(int V, int H, int B, char* base) {
     }
     L.down = plan_split(L.Hpad, cdiv(V, 64), mb, g_ks_down, 16);
     L.down_tr = plan_down_rows(V);
+    L.k2s_tr = g_k2s_tr > 0 ? g_k2s_tr : std::min(48, std::max(8, 8 * cdiv(V, 8 * cu_count())));
     size_t off = 0;
     auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return p; };
     // exactness maps of caller-supplied operands (prep rewrites them every call): visible side, hidden side
@@ -170,7 +174,7 @@ Layout make_layout(int V, int H, int B, char* base) {
     L.cs_hneg = (float*)take((size_t)L.P * H * 4);
     L.cs_vpos = (float*)take((size_t)L.P * V * 4);
     L.cs_vneg = (float*)take((size_t)L.P * V * 4);
-    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, cdiv(V, 16) * (L.Bp / 64)) + IMDBN_MAX_GROUPS * (L.Bp / 64);
+    L.n_loss_slots = std::max(cdiv(std::max(V, H), 64) * L.P, (cdiv(V, 8) + 2) * (L.Bp / 64)) + IMDBN_MAX_GROUPS * (L.Bp / 64);
     L.loss_part = (float*)take((size_t)L.n_loss_slots * 4);
     for (int i = 0; i < 2; ++i) {
         L.vis_tr[i] = (bf16_t*)take((size_t)3 * V * L.Bp * 2);
@@ -268,6 +272,7 @@ struct Ctx {
     int rt;         // terms of a real-valued activation operand
     bool hid_bits_ok = false;      // L.hid_bits describes the current contents of L.hid_rm
     bool data_prepped = false;     // cd_phases: the data-side operands are already in place (prefetch slot)
+    int down_blocks = 0;           // blocks (per batch chunk) of the last K2 launch: the number of squared-error partials it left
     Ctx(const imdbn_rbm_desc* d_, imdbn_rng* r, hipStream_t s_) : d(d_), s(s_), rng(r) {
         nw = d->mode == IMDBN_FAST_BF16 ? 1 : 3;
         rt = nw;
@@ -355,14 +360,21 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
     if (f.T < 1e-6f) f.T = 1e-6f;                           // max(1e-6, T)  rbm.py:92,96
     // lean epilogue specialisation (kernels_ew.hpp finish_rows_impl<R, false>)
     f.simple = (f.T == 1.0f && !(f.sigma > 0.f) && !f.mu && !f.clamp && f.n_groups == 0 && !f.logits_only) ? 1 : 0;
+    // lean epilogue of the streaming kernels (kernels_ew.hpp finish_lean8): decided once all outputs are known (below)
+    auto lean_ok = [&](const FinishArgs& g) {
+        return g.simple && (g.vmode == 0 || g.vmode == 1) && !g.out_prob && !g.out_final && !(g.rm_src && g.op.rm) &&
+               (g.vmode == 0 || g.uni.tape || (g.uni.row0 & 3) == 0) ? 1 : 0;
+    };
     const int mb = L.Bp / 64;
+    // hidden samples (exactly 0/1, not mixed with clamped values) also leave as a bit plane for the fused K2
+    const bool want_hbits = up && f.op.rm == L.hid_rm && f.rm_src == 2 && f.vmode == 1 && !f.clamp && f.n_groups == 0 && !f.logits_only;
     if (up && L.Vpad <= 1024 && !g_no_fused_up) {
         // short K: fused GEMM + epilogue, no split-K slabs (one launch per half step of a chain)
         dim3 grid(cdiv(L.H, 32), 1, mb);
         const int64_t ats = (int64_t)L.Bp * L.Vpad;
         f.dbg = 0;
-        f.op.bits = nullptr;
-        if (f.op.rm == L.hid_rm) c.hid_bits_ok = false;
+        f.op.bits = want_hbits ? L.hid_bits : nullptr; f.op.bits_shape = 1; f.op.bits_cols = 32;      // epilogue lanes: 32 columns x 2 row octets
+        if (f.op.rm == L.hid_rm) c.hid_bits_ok = want_hbits;
         if (c.nw == 3)
             hipLaunchKernelGGL(gemm_up_fused<3>, grid, dim3(256), 0, c.s, d->W, d->ldw, L.V, L.H, in.rm, ats, L.Vpad, in.flag, in.terms, f);
         else
@@ -370,8 +382,6 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         HIPCHK(hipGetLastError());
         return 0;
     }
-    // hidden samples (exactly 0/1, not mixed with clamped values) also leave as a bit plane for the fused K2
-    const bool want_hbits = up && f.op.rm == L.hid_rm && f.rm_src == 2 && f.vmode == 1 && !f.clamp && f.n_groups == 0 && !f.logits_only;
     if (up && in.bits && in.binary && vec4_weights(d) && !g_no_k1s && !f.logits_only) {
         // binary visible operand: weights stream through LDS by LDS-DMA, split-K combined by the last arriver, epilogue fused
         K1sArgs a;
@@ -391,6 +401,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
             HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK + 16));
             attr_done = true;
         }
+        f.lean = lean_ok(f);
         dim3 grid(L.k1s_tiles, a.ks, mb);
         if (c.nw == 3) hipLaunchKernelGGL(k1_stream<3>, grid, dim3(256), lds, c.s, a, f);
         else           hipLaunchKernelGGL(k1_stream<1>, grid, dim3(256), lds, c.s, a, f);
@@ -417,10 +428,48 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         // K2: fused GEMM + epilogue (no split-K slabs)
         if (f.n_groups > 0 && !f.logits_only && !f.out_prob) f.out_prob = L.f_vp, f.ld_prob = L.V;
         if (f.n_groups > 0 && !f.logits_only && !f.out_final) f.out_final = L.f_v[1], f.ld_final = L.V;
+        const uint8_t* hb = (c.hid_bits_ok && in.rm == L.hid_rm && in.terms == 1 && !g_no_bits) ? L.hid_bits : nullptr;
+        if (hb && vec4_weights(d) && !g_no_k2s) {
+            // 0/1 hidden operand as a bit plane: one tile of k2s_tr rows per CU, 16x16x32 MFMA (kernels_stream.hpp)
+            K2sArgs a;
+            memset(&a, 0, sizeof(a));
+            a.W = d->W; a.ldw = d->ldw; a.K = L.H; a.N = L.V; a.abits = hb; a.Bp = L.Bp; a.TR = L.k2s_tr;
+            const int nbx = cdiv(L.Vpad, a.TR), MT = cdiv(a.TR, 16);
+            c.down_blocks = nbx;
+            if ((nbx + IMDBN_MAX_GROUPS) * mb > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
+            f.dbg = g_dbg;
+            if (f.op.bits && (f.n_groups > 0 || f.vmode == 0)) f.op.bits = nullptr;      // not a pure 0/1 sample
+            f.lean = lean_ok(f);
+            const int nsteps = cdiv(L.H, 32);
+            size_t lds = (size_t)((nsteps * 256 + 255) & ~255) + (size_t)4 * 16 * MT * K2S_LDR * 4;
+            if (next) lds = std::max(lds, (size_t)3 * 4 * 64 * 16 * 2);      // prep_item_body's stage
+            PrepArgs pz;
+            memset(&pz, 0, sizeof(pz));
+            dim3 grid(nbx + (next ? cdiv(std::max(next->N, next->op.ldrm), 64) : 0), 1, mb);
+            hipError_t le = hipSuccess;
+#define LAUNCH_K2S(NW, MTV, NX) do { \
+        static bool attr = false; \
+        if (!attr) { le = hipFuncSetAttribute((const void*)k2_stream<NW, MTV, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        if (le == hipSuccess) hipLaunchKernelGGL((k2_stream<NW, MTV, NX>), grid, dim3(256), lds, c.s, a, f, next ? *next : pz, nbx); } while (0)
+#define LAUNCH_K2S_M(NW, NX) do { if (MT == 1) LAUNCH_K2S(NW, 1, NX); else if (MT == 2) LAUNCH_K2S(NW, 2, NX); else LAUNCH_K2S(NW, 3, NX); } while (0)
+            if (lds > 160 * 1024) return fail(IMDBN_E_UNSUPPORTED, "internal: k2_stream LDS");
+            if (c.nw == 3) { if (next) LAUNCH_K2S_M(3, true); else LAUNCH_K2S_M(3, false); }
+            else           { if (next) LAUNCH_K2S_M(1, true); else LAUNCH_K2S_M(1, false); }
+#undef LAUNCH_K2S_M
+#undef LAUNCH_K2S
+            HIPCHK(le);
+            HIPCHK(hipGetLastError());
+            if (f.n_groups > 0 && !f.logits_only) {
+                hipLaunchKernelGGL(finish_groups, dim3(f.n_groups, L.Bp / 64), dim3(256), 0, c.s, f, (int)(nbx * mb));
+                HIPCHK(hipGetLastError());
+            }
+            return 0;
+        }
         // tiles cover [0, Vpad): the K16-blocked operand form must have its padding columns [V, Vpad) written (zeros) -- the
         // next K1 multiplies them with clamped (non-zero) weight rows.  Tiles of 20 / 24 / 28 rows (chosen for V in
         // (4096, 7168]) do not end on a multiple of 16 by themselves; found by tools/stress_parity.py.
         dim3 grid(cdiv(L.Vpad, L.down_tr), 1, mb);
+        c.down_blocks = (int)grid.x;
         f.dbg = g_dbg;
         if (f.op.bits && (L.down_tr % 8 != 0 || f.n_groups > 0 || f.vmode == 0)) f.op.bits = nullptr;      // not a 0/1 plane the epilogue can write byte-wise
         f.op.bits_shape = 1; f.op.bits_cols = L.down_tr;
@@ -472,9 +521,12 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
     }
     return 0;
 }
+// k2_stream runs the K2 of a CD pass (its hidden operand is always a sample with a bit plane) whenever the weight rows allow
+bool k2s_for_cd(const imdbn_rbm_desc* d) { return vec4_weights(d) && !g_no_k2s && !g_no_bits; }
 int n_loss_used(const Ctx& c, bool up) {
     if (up) return cdiv(c.L.H, 64) * c.L.P;
-    return (cdiv(c.L.Vpad, c.L.down_tr) + c.d->n_groups) * (c.L.Bp / 64);    // fused K2: one partial per block (+ per group block)
+    const int blocks = c.down_blocks > 0 ? c.down_blocks : cdiv(c.L.Vpad, k2s_for_cd(c.d) ? c.L.k2s_tr : c.L.down_tr);
+    return (blocks + c.d->n_groups) * (c.L.Bp / 64);    // fused K2: one partial per block (+ per group block)
 }
 
 // caller fp32 tensor -> operand forms in the workspace
@@ -579,7 +631,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
     if (o->cd_k < 1) return fail(IMDBN_E_INVALID, "CD=%d (the reference needs CD>=1, rbm.py:204-209)", o->cd_k);
     if (!c.data_prepped) CHK(prep(c, data, ldd, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], L.flags, L.cs_vpos, 3, L.vis_bits[0]));
     // the visible sample of the negative phase leaves the fused K2 as a bit plane too when its tiles are whole bytes wide
-    const bool vbits = c.d->n_groups == 0 && L.down_tr % 8 == 0;
+    const bool vbits = c.d->n_groups == 0 && (k2s_for_cd(c.d) || L.down_tr % 8 == 0);
     const bool k1s_neg = vec4_weights(c.d) && !g_no_k1s && L.Vpad > 1024;      // the negative-phase K1 will be k1_stream (prop())
     // positive phase: P+ = up(data); h = 1[P+ > U]
     {
@@ -814,6 +866,8 @@ int imdbn_set_option(const char* name, int value) {
     else if (!strcmp(name, "dbg")) g_dbg = value;
     else if (!strcmp(name, "no_k1s")) g_no_k1s = value;
     else if (!strcmp(name, "k1s_ks")) g_k1s_ks = std::max(0, value);
+    else if (!strcmp(name, "no_k2s")) g_no_k2s = value;
+    else if (!strcmp(name, "k2s_rows")) { if (value != 0 && (value < 8 || value > 48 || value % 8)) return fail(IMDBN_E_INVALID, "k2s_rows must be 0 or a multiple of 8 in [8, 48]"); g_k2s_tr = value; }
     else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
     else if (!strcmp(name, "no_fused_up")) g_no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);

@@ -27,18 +27,20 @@ struct OperandOut {
     // bit-packed form of an exactly-{0,1} operand (sampled states, binary data), BYTE-major: bits[(k >> 3)*Bp + b] bit (k & 7):
     // the 8 k-values of one MFMA fragment lane are one byte, any 8-column-aligned tile can write its part, and a wave's loads
     // of one K block are contiguous.  16x smaller than the bf16 form.  bits_shape: how the lanes of a wave map to columns in
-    // the writing kernel -- 0: 64 consecutive columns (finish, prep), 1: 32 consecutive columns x 2 row groups (lanes >= 32)
+    // the writing kernel -- 0: 64 consecutive columns (finish, prep), 1: 32 consecutive columns x 2 row groups (lanes >= 32),
+    // 2: 16 consecutive columns x 4 row groups
     uint8_t* bits; int bits_shape; int bits_cols;      // bits_cols (shape 1): valid columns of the 32-column run (multiple of 8)
 };
 
 // row `b` of a 0/1 operand for the columns the wave covers -> bit plane (one byte per 8 columns).  nz = this lane's value != 0.
-__device__ __forceinline__ void store_bits_row(const OperandOut& o, bool nz, int col, int b, bool row_ok) {
+__device__ __forceinline__ void store_bits_row(const OperandOut& o, bool nz, int col, int b, bool row_ok, int shape, int cols) {
     const unsigned long long m = __ballot(nz ? 1 : 0);
     const int lane = threadIdx.x & 63;
     int j, shift, colbase;
     bool w;
-    if (o.bits_shape == 0) { j = lane; w = lane < 8; shift = 8 * lane; colbase = col - lane; }
-    else { j = lane & 31; w = j < (o.bits_cols >> 3); shift = 32 * (lane >> 5) + 8 * j; colbase = col - j; }
+    if (shape == 0) { j = lane; w = lane < 8; shift = 8 * lane; colbase = col - lane; }
+    else if (shape == 1) { j = lane & 31; w = j < (cols >> 3); shift = 32 * (lane >> 5) + 8 * j; colbase = col - j; }
+    else { j = lane & 15; w = j < (cols >> 3); shift = 16 * (lane >> 4) + 8 * j; colbase = col - j; }
     if (w && row_ok) o.bits[(int64_t)((colbase >> 3) + j) * o.Bp + b] = (uint8_t)((m >> (shift & 63)) & 0xFFull);
 }
 
@@ -148,6 +150,9 @@ struct FinishArgs {
     float* colsum_part; int colsum_src;            // [Bp/32][N]
     const float* loss_ref; int64_t ld_ref; int loss_src; float* loss_part;   // one per block (+ one per group)
     int simple;                                    // set by the host: none of T / noise / mu / clamp / groups / logits_only in use
+    int lean;                                      // set by the host: `simple`, no fp32 outputs, no K16-blocked form, draws from a tape or from Philox with
+                                                   // row0 % 4 == 0: the streaming kernels then run finish_lean8 (a few hundred instructions instead of
+                                                   // the general epilogue's many inlined variants, whose code alone overflowed the instruction cache)
     int dbg;                                       // tuning aid: which kernels record per-block timeline stamps (common.hpp stamp)
 };
 
@@ -200,7 +205,7 @@ __device__ __forceinline__ void load_side(const FinishArgs& a, int col, int b0, 
 // epilogue).  Sampling (vmode) stays a run-time switch in both.
 template <int R, bool EX>
 __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, int b0, const float (&xs)[R], const SideIn<R>& sd, float& csum,
-                                                  const RmStage* stg) {
+                                                  const RmStage* stg, int bshape, int bcols) {
     const bool cok = col < a.N;
     const bool grp = EX && cok && in_group(a, col);
     const int cc = min(col, a.N - 1);
@@ -276,16 +281,16 @@ __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, 
     //  finish_groups, which runs after this kernel)
     if (a.op.bits) {                  // block-uniform; the wave's lanes cover aligned runs of 64 (or 2 x 32) consecutive columns
 #pragma unroll
-        for (int i = 0; i < R; ++i) store_bits_row(a.op, xf[i] != 0.f, col, b0 + i, b0 + i < a.Bp);
+        for (int i = 0; i < R; ++i) store_bits_row(a.op, xf[i] != 0.f, col, b0 + i, b0 + i < a.Bp, bshape < 0 ? a.op.bits_shape : bshape, bshape < 0 ? a.op.bits_cols : bcols);
     }
     return lsum;
 }
 
 template <int R>
 __device__ __forceinline__ float finish_rows(const FinishArgs& a, int col, int b0, const float (&xs)[R], const SideIn<R>& sd, float& csum,
-                                             const RmStage* stg = nullptr) {
-    if (a.simple) return finish_rows_impl<R, false>(a, col, b0, xs, sd, csum, stg);
-    return finish_rows_impl<R, true>(a, col, b0, xs, sd, csum, stg);
+                                             const RmStage* stg = nullptr, int bshape = -1, int bcols = 0) {
+    if (a.simple) return finish_rows_impl<R, false>(a, col, b0, xs, sd, csum, stg, bshape, bcols);
+    return finish_rows_impl<R, true>(a, col, b0, xs, sd, csum, stg, bshape, bcols);
 }
 
 template <int R>
@@ -297,9 +302,9 @@ __device__ __forceinline__ float finish_rows(const FinishArgs& a, int col, int b
 
 // one column x 8 rows per thread: part_row = index of this 8-row group in the column-sum partials
 __device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int b0, const float (&xs)[8], int part_row, const SideIn<8>& sd,
-                                              const RmStage* stg = nullptr) {
+                                              const RmStage* stg = nullptr, int bshape = -1, int bcols = 0) {
     float csum;
-    const float lsum = finish_rows<8>(a, col, b0, xs, sd, csum, stg);
+    const float lsum = finish_rows<8>(a, col, b0, xs, sd, csum, stg, bshape, bcols);
     if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
     return lsum;
 }
@@ -307,6 +312,65 @@ __device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int 
     float csum;
     const float lsum = finish_rows<8>(a, col, b0, xs, csum);
     if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
+    return lsum;
+}
+
+// ---- lean epilogue of the CD propagations: one column x 8 consecutive batch rows (b0 % 8 == 0) --------------------------
+// Exactly the arithmetic (and summation order) of finish_rows_impl<8, false> for the configurations the CD step uses:
+// T = 1, no noise / mu-pull / clamp / softmax groups, outputs = transposed operand plane(s), bit plane of the sample,
+// column-sum partial, squared-error partial.  Side inputs: the bias and (with a loss reference) 8 reference values.
+struct SideLean { float bias; float ref[8]; };
+
+__device__ __forceinline__ void load_side_lean(const FinishArgs& a, int col, int b0, SideLean& s) {
+    const int cc = min(col, a.N - 1);
+    s.bias = a.bias[cc];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s.ref[i] = a.loss_ref ? a.loss_ref[(int64_t)min(b0 + i, a.B - 1) * a.ld_ref + cc] : 0.f;
+}
+
+__device__ __forceinline__ float finish_lean8(const FinishArgs& a, int col, int b0, const float (&xs)[8], int part_row, const SideLean& sd,
+                                              int bshape, int bcols) {
+    const bool cok = col < a.N;
+    const int cc = min(col, a.N - 1);
+    const int vmode = a.vmode, colsum_src = a.colsum_src, loss_src = a.loss_src;
+    const bool has_ref = a.loss_ref != nullptr;
+    float us[8];
+    if (vmode != 0) {
+        if (a.uni.tape) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) us[i] = a.uni.tape[(int64_t)min(b0 + i, a.B - 1) * a.uni.N + cc];
+        } else {                                   // row0 % 4 == 0 (host): the 8 rows are two whole 4-row Philox groups
+            const uint64_t g0 = (uint64_t)(a.uni.row0 + b0);
+            const uint4 x = draw_block4(a.uni, g0, cc), y = draw_block4(a.uni, g0 + 4, cc);
+            us[0] = u24(x.x); us[1] = u24(x.y); us[2] = u24(x.z); us[3] = u24(x.w);
+            us[4] = u24(y.x); us[5] = u24(y.y); us[6] = u24(y.z); us[7] = u24(y.w);
+        }
+    }
+    float xp[8], xf[8];
+    float csum = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool live = cok && (b0 + i) < a.B;
+        const float p = sigmoidf_ref(xs[i] + sd.bias);
+        const float v = vmode == 0 ? p : ((p > us[i]) ? 1.f : 0.f);
+        xp[i] = live ? p : 0.f;
+        xf[i] = live ? v : 0.f;
+        if (live) {
+            csum += (colsum_src == 2 ? v : p);
+            const float dlt = sd.ref[i] - (loss_src == 2 ? v : p);
+            lsum += has_ref ? dlt * dlt : 0.f;
+        }
+    }
+    if (a.tr_src) {
+        uint32_t pc[3][8];
+        pieces<8>(a.tr_src == 2 ? xf : xp, a.op.tr_terms, pc);
+        store_tr_pc<8>(a.op, pc, b0, col, a.N, a.Bp);
+    }
+    if (a.op.bits) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) store_bits_row(a.op, xf[i] != 0.f, col, b0 + i, b0 + i < a.Bp, bshape, bcols);
+    }
+    if (a.colsum_part && cok) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
     return lsum;
 }
 
@@ -551,7 +615,7 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
         csum += x[i];
         inexact |= (__float_as_uint(x[i]) & 0xFFFFu) != 0u;
         nonbin |= (x[i] != 0.f && x[i] != 1.0f);
-        if (a.op.bits) store_bits_row(a.op, x[i] != 0.f, col, b, b < a.Bp);
+        if (a.op.bits) store_bits_row(a.op, x[i] != 0.f, col, b, b < a.Bp, 0, 64);
     }
     const bool any = __any(inexact ? 1 : 0) != 0, anyb = __any(nonbin ? 1 : 0) != 0;
     if (c == 0) fl[kq] = (any ? FLAG_INEXACT : 0) | (anyb ? FLAG_NONBINARY : 0);
@@ -600,7 +664,7 @@ __device__ __forceinline__ void prep_item_body(const PrepArgs& a, int tx, int mb
             x[i] = (col < a.N && b0 + i < a.B) ? v[8 * hf + i] : 0.f;
             inexact |= (__float_as_uint(x[i]) & 0xFFFFu) != 0u;
             nonbin |= (x[i] != 0.f && x[i] != 1.0f);
-            if (a.op.bits) store_bits_row(a.op, x[i] != 0.f, col, b0 + i, true);
+            if (a.op.bits) store_bits_row(a.op, x[i] != 0.f, col, b0 + i, true, 0, 64);
         }
         // the order of prep_operand: four row pairs, combined left to right
         const float csum = (((0.f + x[0] + x[1]) + (0.f + x[2] + x[3])) + (0.f + x[4] + x[5])) + (0.f + x[6] + x[7]);

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     // latency would otherwise sit behind the split-K combine
     const int ecol = (n0 + (tid & 31) < a.N) ? n0 + (tid & 31) : (1 << 30);
     SideIn<8> side;
-    load_side<8>(fa, ecol, mb + 8 * (tid >> 5), side);
+    SideLean sl8;
+    if (fa.lean) load_side_lean(fa, ecol, mb + 8 * (tid >> 5), sl8);
+    else         load_side<8>(fa, ecol, mb + 8 * (tid >> 5), side);
 #pragma unroll
     for (int d = 0; d < K1S_D; ++d) issue_slot(d, d);
     // the bits (issued first) have landed once at most the ring's instructions are outstanding
@@ -200,8 +202,179 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     }
     stamp(st, sblk, 5);
     // ---- epilogue of `finish`, fused: bias, sigmoid, Bernoulli sample, operand forms, column sums
-    (void)finish_rows8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, side, nullptr);
+    if (fa.lean) (void)finish_lean8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, sl8, 1, 32);
+    else         (void)finish_rows8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, side, nullptr);
     stamp(st, sblk, 6);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+//   k2_stream   K2  v = sample(sigmoid(h W^T + b)) for a 0/1 hidden operand (rbm.py:96-135, :205-206), epilogue fused.
+//
+// W is [N][K] here (N = visible units = rows of W, K = hidden units, contiguous): a block owns TR whole rows, TR chosen
+// so that the tiles are dealt ONE per CU (TR = 40 -> 250 blocks at 10000 rows; the 32-wide tiles of gemm_down_fused
+// put two 24-row tiles on most CUs and one on the rest: its K loop took 11 us on some CUs and 16 us on others).  TR is
+// not a multiple of 32, so the MFMA is v_mfma_f32_16x16x32_bf16 with the WEIGHT rows as the M dimension (ceil(TR/16) tiles,
+// the last one partly idle) and the batch as N (4 tiles of 16 rows): a lane's A fragment = 8 consecutive k of one weight
+// row = two adjacent float4 loads, a wave-instruction = 16 rows x 128 B.  Four waves split K (32-wide steps dealt round
+// robin) behind a 3-deep register ring; the activations are the byte-major bit plane, staged once in LDS.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int K2S_D = 3;                          // register ring depth (K32 steps) per wave
+constexpr int K2S_LDR = 68;                       // row pitch (floats) of the reduction buffer red[4][48][K2S_LDR]
+
+struct K2sArgs {
+    const float* W; int64_t ldw; int K, N;        // W[N][ldw]: N rows (visible units), K valid columns (hidden units), K % 4 == 0
+    const uint8_t* abits; int Bp;                 // hidden sample: byte-major bit plane [rup(K,64)/8][Bp]
+    int TR;                                       // rows per block: multiple of 8, <= 16 MT
+};
+
+template <int MT>
+struct K2sOps { float4 w[MT][2]; };
+
+template <int NW, int MT, bool NEXT>
+__device__ __forceinline__ void k2s_body(const K2sArgs& a, const FinishArgs& fa, char* smem, int bx, int bz, int nbx) {
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, m = l & 15, kg = l >> 4;
+    const int TR = a.TR, v0 = bx * TR, mb = bz * 64;
+    const int nsteps = (a.K + 31) / 32;                       // K32 steps; wave w takes steps w, w + 4, ...
+    const int my = (nsteps - w + 3) / 4;
+    uint8_t* hbl = reinterpret_cast<uint8_t*>(smem);          // [nsteps * 4][64] activation bytes of this batch chunk
+    float* red = reinterpret_cast<float*>(smem + ((nsteps * 4 * 64 + 255) & ~255));      // [4][16 MT][K2S_LDR]
+
+    // ---- hidden bits -> LDS: 16-B pieces, plain loads (12 KB at K = 1500)
+    {
+        const int n16 = nsteps * 4 * 4;                       // 16-B pieces: byte-row r, quarter q
+        const int last_row = (a.K + 63) / 64 * 8 - 1;
+        for (int i = tid; i < n16; i += 256) {
+            const int r = i >> 2, q = i & 3;
+            *reinterpret_cast<uint4*>(hbl + r * 64 + 16 * q) =
+                *reinterpret_cast<const uint4*>(a.abits + (int64_t)min(r, last_row) * a.Bp + mb + 16 * q);
+        }
+    }
+    // ---- weight ring: all loads unconditional from clamped addresses (steps past the wave's last one re-read it: L2 hits)
+    const float* wrow[MT];
+    const int vlast = min(v0 + TR, a.N) - 1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wrow[mt] = a.W + (int64_t)min(v0 + 16 * mt + m, vlast) * a.ldw;
+    auto load = [&](K2sOps<MT>& o, int i) {                   // wave-local step i
+        const int k0 = 32 * (4 * max(min(i, my - 1), 0) + w) + 8 * kg;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            o.w[mt][0] = *reinterpret_cast<const float4*>(wrow[mt] + min(k0, a.K - 4));
+            o.w[mt][1] = *reinterpret_cast<const float4*>(wrow[mt] + min(k0 + 4, a.K - 4));
+        }
+    };
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const K2sOps<MT>& o, int i) {
+        const int step = 4 * i + w;
+        uint4 bf[4];                                          // batch fragments: k = 32 step + 8 kg + j of batch row 16 nt + m
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = bits_to_frag(hbl[(4 * step + kg) * 64 + 16 * nt + m]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float x[8] = {o.w[mt][0].x, o.w[mt][0].y, o.w[mt][0].z, o.w[mt][0].w, o.w[mt][1].x, o.w[mt][1].y, o.w[mt][1].z, o.w[mt][1].w};
+            uint4 af[NW];
+            make_w_frags<NW>(x, af);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int tw = 0; tw < NW; ++tw)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[tw]), as_frag(bf[nt]), acc[mt][nt], 0, 0, 0);
+        }
+    };
+    K2sOps<MT> ring[K2S_D];
+    const bool st = (fa.dbg & 128) != 0;
+    const int sblk = bz * nbx + bx;
+    stamp(st, sblk, 0);
+    // epilogue side inputs of pass A (columns 0..31 of the tile): requested before the K loop
+    const int cA = tid & 31, octA = tid >> 5;
+    const int ecolA = (cA < TR) ? v0 + cA : (1 << 30);
+    SideIn<8> sideA;
+    SideLean slA, slB;
+    const int cB = 32 + (tid & 15), octB = tid >> 4;          // pass B: waves 0, 1
+    const int ecolB = (cB < TR) ? v0 + cB : (1 << 30);
+    if (fa.lean) {
+        load_side_lean(fa, ecolA, mb + 8 * octA, slA);
+        if (MT == 3 && TR > 32 && w < 2) load_side_lean(fa, ecolB, mb + 8 * octB, slB);
+    } else {
+        load_side<8>(fa, ecolA, mb + 8 * octA, sideA);
+    }
+#pragma unroll
+    for (int d = 0; d < K2S_D; ++d) load(ring[d], d);
+    __syncthreads();                                          // the activation bytes are in LDS
+    stamp(st, sblk, 1);
+    for (int g = 0; g * K2S_D < my; ++g) {
+#pragma unroll
+        for (int d = 0; d < K2S_D; ++d) {
+            const int i = g * K2S_D + d;
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < my) compute(ring[d], i);                  // wave-uniform
+            __builtin_amdgcn_sched_barrier(0);
+            load(ring[d], i + K2S_D);
+        }
+    }
+    stamp(st, sblk, 2);
+    // ---- cross-wave reduction: C tile (mt, nt): lane holds batch row 16 nt + m, weight rows 16 mt + 4 kg + reg
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) red[(w * 16 * MT + 16 * mt + 4 * kg + reg) * K2S_LDR + 16 * nt + m] = acc[mt][nt][reg];
+    __syncthreads();
+    stamp(st, sblk, 3);
+    float lsum = 0.f;
+    // pass A: columns 0 .. 31 (lanes = 32 columns x 2 row octets); pass B: columns 32 .. 47 (16 columns x 4 octets, waves 0, 1)
+    {
+        float xs[8];
+        const float* p = red + cA * K2S_LDR + 8 * octA;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            xs[i] = ((p[i] + p[16 * MT * K2S_LDR + i]) + p[2 * 16 * MT * K2S_LDR + i]) + p[3 * 16 * MT * K2S_LDR + i];
+        if (fa.lean) lsum += finish_lean8(fa, ecolA, mb + 8 * octA, xs, (mb >> 3) + octA, slA, 1, min(TR, 32));
+        else         lsum += finish_rows8(fa, ecolA, mb + 8 * octA, xs, (mb >> 3) + octA, sideA, nullptr, 1, min(TR, 32));
+    }
+    if constexpr (MT == 3) {
+        if (TR > 32 && w < 2) {                               // wave-uniform
+            SideIn<8> sideB;
+            if (!fa.lean) load_side<8>(fa, ecolB, mb + 8 * octB, sideB);
+            float xs[8];
+            const float* p = red + cB * K2S_LDR + 8 * octB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xs[i] = ((p[i] + p[16 * MT * K2S_LDR + i]) + p[2 * 16 * MT * K2S_LDR + i]) + p[3 * 16 * MT * K2S_LDR + i];
+            if (fa.lean) lsum += finish_lean8(fa, ecolB, mb + 8 * octB, xs, (mb >> 3) + octB, slB, 2, TR - 32);
+            else         lsum += finish_rows8(fa, ecolB, mb + 8 * octB, xs, (mb >> 3) + octB, sideB, nullptr, 2, TR - 32);
+        }
+    }
+    stamp(st, sblk, 4);
+    if (fa.loss_part) {
+        __syncthreads();                                      // red is consumed
+        const float t = wave_sum(lsum);
+        if (l == 0) red[w] = t;
+        __syncthreads();
+        if (tid == 0) fa.loss_part[bz * nbx + bx] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+    stamp(st, sblk, 5);
+}
+
+// NEXT: the launch carries the preparation of the following batch as extra blocks behind its `main_nbx` weight tiles
+// (prep_item_body: operand forms, bit plane, exactness map, column sums of imdbn_cd_opts.next_data)
+template <int NW, int MT, bool NEXT>
+__global__ __launch_bounds__(256, 2) void k2_stream(const K2sArgs a, const FinishArgs fa, const PrepArgs next, int main_nbx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (NEXT) {
+        if ((int)blockIdx.x >= main_nbx) {
+            prep_item_body(next, blockIdx.x - main_nbx, blockIdx.z, reinterpret_cast<bf16_t*>(smem));
+            return;
+        }
+    }
+    k2s_body<NW, MT, NEXT>(a, fa, smem, blockIdx.x, blockIdx.z, main_nbx);
 }
 
 }  // namespace imdbn

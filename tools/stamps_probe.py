@@ -17,10 +17,9 @@ eng = E.get_hip_engine()
 rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
 x = (torch.rand(B, V) > 0.9).float().to(dev)
 E.set_rng(E.PhiloxRng(seed=2))
-for which, bit, nslots in (("K1 k1_stream (last launch = negative phase): start, bits+ring landed, loop done, reduced, published, [last arriver:] combined, epilogue done", 64, 7), ("K2 down_fused", 128, 8),
-                           ("K2 down_fused, no operand stores", 128 + 1024, 7), ("K2 down_fused, no sigmoid", 128 + 2048, 7),
-                           ("K2 down_fused, neither", 128 + 1024 + 2048, 7),
-                           ("finish (last launch = hidden, negative phase)", 256, 4), ("K3 assoc_update_planes", 512, 6)):
+for which, bit, nslots in (("K1 k1_stream (last launch = negative phase): start, bits+ring landed, loop done, reduced, published, [last arriver:] combined, epilogue done", 64, 7),
+                           ("K2 k2_stream: start, bits staged, loop done, reduced, epilogue done, loss done", 128, 6),
+                           ("K3 assoc_update_planes", 512, 6)):
     eng.set_option("dbg", bit)
     for i in range(20):
         rbm.train_epoch(x, 0, 1, CD=1)

@@ -122,6 +122,10 @@ typedef struct imdbn_cd_opts {
      * the batch as a bit plane (imdbn_rbm_cd_step / _cd_stats / _cd_factors).  The assertion is checked on the device; a batch
      * that is not binary turns the update into NaN instead of being silently truncated.  0: no assumption. */
     int32_t data_binary;
+    /* -- 1: the same assertion for `next_data`: its preparation then writes only what a binary batch needs (bit plane,
+     * exactness map, column sums, one bf16 plane) instead of all three-term operand forms.  Honoured only when the positive
+     * phase can read bit planes (16-B aligned weight rows, V > 1024); the later cd_step on that batch must pass data_binary = 1. */
+    int32_t next_binary;
 } imdbn_cd_opts;
 
 /* ---- plumbing ------------------------------------------------------------------------- */

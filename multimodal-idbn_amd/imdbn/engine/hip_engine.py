@@ -312,6 +312,7 @@ class HipEngine:
                 and tuple(next_data.shape) == tuple(x.shape) and next_data.stride(1) == 1 and self.prefetch_ok(d, B)):
             nxt = next_data
             o.next_data, o.ld_next, o.next_slot = nxt.data_ptr(), nxt.stride(0), (2 if o.data_slot == 1 else 1)
+            o.next_binary = int(self.data_is_binary(next_data))
         N.check(self._lib.imdbn_rbm_cd_step(C.byref(d), _ptr(x), x.stride(0), B, C.byref(o), C.byref(r), _ptr(loss),
                                              _ptr(ws), ws.numel(), self._stream(dev)), "imdbn_rbm_cd_step")
         self._done(rng, r, sched)

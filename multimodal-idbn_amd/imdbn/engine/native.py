@@ -48,7 +48,7 @@ class CdOpts(C.Structure):
                 ("sparsity", C.c_int32), ("sparsity_target", C.c_float),
                 ("sample_h", C.c_int32), ("sample_v", C.c_int32), ("reclamp_negative", C.c_int32),
                 ("next_data", C.c_void_p), ("ld_next", C.c_int64), ("next_slot", C.c_int32), ("data_slot", C.c_int32),
-                ("data_binary", C.c_int32)]
+                ("data_binary", C.c_int32), ("next_binary", C.c_int32)]
 
 
 _P = C.c_void_p

@@ -361,14 +361,36 @@ def case_imdbn_small():
 
     m._cross_reconstruct = cr
     out = {}
-    with Substitute(s) as sub:
-        sub._vshape = sizes[-1] + K
-        m.image_idbn.train(1)
-        for i, r in enumerate(m.image_idbn.layers):
-            for k, v in state_of(r).items():
-                out[f"img{i}_{k}"] = v
-        m.train_joint(10)            # epochs 0-7 warm-up, 8-9 main phase
+    # the reference's online metrics (imdbn.py:615-639) only reach wandb: record what its own F.binary_cross_entropy /
+    # F.mse_loss calls return (nothing else in train_joint calls them), and redo its argmax / topk on the recorded p_y
+    import torch.nn.functional as Fn
+    ce_vals, mse_vals = [], []
+    o_bce, o_mse = Fn.binary_cross_entropy, Fn.mse_loss
+    Fn.binary_cross_entropy = lambda *a, **k: (lambda v: (ce_vals.append(float(v)), v)[1])(o_bce(*a, **k))
+    Fn.mse_loss = lambda *a, **k: (lambda v: (mse_vals.append(float(v)), v)[1])(o_mse(*a, **k))
+    try:
+        with Substitute(s) as sub:
+            sub._vshape = sizes[-1] + K
+            m.image_idbn.train(1)
+            for i, r in enumerate(m.image_idbn.layers):
+                for k, v in state_of(r).items():
+                    out[f"img{i}_{k}"] = v
+            m.train_joint(10)            # epochs 0-7 warm-up, 8-9 main phase
+    finally:
+        Fn.binary_cross_entropy, Fn.mse_loss = o_bce, o_mse
     del m.joint_rbm.train_epoch, m._cross_reconstruct
+    assert len(ce_vals) == len(mse_vals) == len(cross) == 10 * NB, (len(ce_vals), len(mse_vals), len(cross))
+    met = np.zeros((10, 4), np.float64)      # per epoch: text_top1, text_top3, text_ce, image_mse  (imdbn.py:648-657)
+    for e in range(10):
+        n = top1 = top3 = 0
+        for b in range(NB):
+            py = torch.from_numpy(cross[e * NB + b][1])
+            gt = torch.from_numpy(Y[b * B:(b + 1) * B]).argmax(dim=1)
+            top1 += int((py.argmax(dim=1) == gt).sum())
+            top3 += int((py.topk(k=min(3, py.size(1)), dim=1).indices == gt.unsqueeze(1)).any(dim=1).sum())
+            n += py.size(0)
+        met[e] = (top1 / n, top3 / n, sum(ce_vals[e * NB:(e + 1) * NB]) / n, sum(mse_vals[e * NB:(e + 1) * NB]) / max(1, n * 100))
+    out["joint_metrics"] = met
     for k, v in state_of(m.joint_rbm).items():
         out["joint_" + k] = v
     out["z_class_mean"] = m.z_class_mean.numpy()
@@ -492,11 +514,58 @@ def case_c2_digest():
          hb_m=st["hb_m"], vb_m=st["vb_m"], **out)
 
 
+# ---------------------------------------------------------------------------
+# load_pretrained_image_idbn + finetune_image_last_layer (imdbn.py:294-384)  (a17)
+# ---------------------------------------------------------------------------
+def case_pretrained_finetune():
+    """A fresh iMDBN loads the reference-written iDBN pickle (tests/golden/ref_idbn_small.pkl, dict form), which re-binds the
+    layer tensors and re-zeros the momentum buffers, then fine-tunes the last image layer for 2 epochs at lr x 0.3."""
+    seed = 505
+    s = DrawStream(seed)
+    sizes, JH, K = [100, 40, 20], 16, 8
+    B, NB = 8, 6
+    N = B * NB
+    yi = (np.arange(N) * 3) % K
+    X = (s.uniform((N, 100)) > 0.75).astype(np.float32)
+    Y = np.eye(K, dtype=np.float32)[yi]
+    dl = _loader(X, Y, B)
+    m = iMDBN(sizes, JH, params=dict(PARAMS), dataloader=dl, val_loader=dl, device=torch.device("cpu"), num_labels=K)
+    old_layers = list(m.image_idbn.layers)
+    assert m.load_pretrained_image_idbn(os.path.join(HERE, "ref_idbn_small.pkl")) is True
+    assert m.image_idbn.layers[0] is not old_layers[0]
+    out = {}
+    for i, r in enumerate(m.image_idbn.layers):
+        assert float(r.W_m.abs().sum()) == 0.0 and float(r.hb_m.abs().sum()) == 0.0      # momentum re-zeroed (imdbn.py:329-331)
+        out[f"loaded{i}_W_sum"] = np.float64(r.W.detach().double().sum())
+    last = m.image_idbn.layers[-1]
+    lr0 = float(last.lr)
+    losses = []
+    o_te = last.train_epoch
+    last.train_epoch = lambda *a, **k: (lambda L: (losses.append(float(L)), L)[1])(o_te(*a, **k))
+    with Substitute(s) as sub:
+        m.finetune_image_last_layer(epochs=2, lr_scale=0.3)
+    del last.train_epoch
+    assert float(last.lr) == lr0                                                          # restored (imdbn.py:383)
+    for k, v in state_of(last).items():
+        out["last_" + k] = v
+    for k, v in state_of(m.image_idbn.layers[0]).items():
+        out["first_" + k] = v                                                             # untouched by the fine-tuning
+    save("pretrained_finetune_100_40_20.npz",
+         dict(seed=seed, sizes=sizes, joint_hidden=JH, K=K, B=B, NB=NB, params=PARAMS, epochs=2, lr_scale=0.3, lr0=lr0,
+              min_margin=sub.min_margin, draw_log_len=len(s.log),
+              recipe="s=DrawStream(seed); X=(s.uniform(N,100)>.75); iMDBN(...).load_pretrained_image_idbn(ref_idbn_small.pkl); "
+                     "finetune_image_last_layer(epochs=2, lr_scale=0.3)"),
+         yi=yi.astype(np.int32), losses=np.array(losses, np.float32), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c1", "joint", "idbn", "imdbn", "bimodal", "c2"]
+    # torch.multinomial draws from torch's global generator (seeded above): the recorded categorical indices -- and with them
+    # every later number -- depend on the ORDER of the cases; regenerate with all cases in this order ("pretrained" last)
+    which = sys.argv[1:] or ["c1", "joint", "idbn", "imdbn", "bimodal", "c2", "pretrained"]
     if "c1" in which: case_c1()
     if "joint" in which: case_joint_small()
     if "idbn" in which: case_idbn_small()
     if "imdbn" in which: case_imdbn_small()
     if "bimodal" in which: case_bimodal_small()
     if "c2" in which: case_c2_digest()
+    if "pretrained" in which: case_pretrained_finetune()

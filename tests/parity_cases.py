@@ -247,9 +247,51 @@ def case_imdbn_small(dev, rel=3e-4):
         assert_close(N(a), fx["xr_nomu_img"], rel, "xr nomu img"); assert_close(N(b), fx["xr_nomu_py"], rel, "xr nomu p_y")
         mdl.z_class_mean = zcm
     assert s.exhausted_cat()
-    # online metrics exist for every epoch and are sane
+    # online metrics (imdbn.py:615-657) against the values the reference itself computed, epoch by epoch
     assert len(mdl.joint_history) == m["joint_epochs"]
-    assert all(0.0 <= h["text_top1"] <= h["text_top3"] <= 1.0 for h in mdl.joint_history)
+    got = np.array([[h["text_top1"], h["text_top3"], h["text_ce"], h["image_mse"]] for h in mdl.joint_history])
+    want = fx["joint_metrics"]
+    n = B * NB
+    assert np.abs(got[:, :2] - want[:, :2]).max() <= 1.0 / n + 1e-12, "top-1 / top-3 differ by more than one sample"
+    assert_close(got[:, 2], want[:, 2], 2e-4, "text CE per epoch")
+    assert_close(got[:, 3], want[:, 3], 2e-4, "image MSE per epoch")
+    return mdl
+
+
+def case_pretrained_finetune(dev, rel=1e-4):
+    """a17 (imdbn.py:294-384): load_pretrained_image_idbn on the reference-written pickle re-binds the layer tensors and
+    re-zeros the momentum buffers; finetune_image_last_layer trains the last layer at lr x lr_scale on the lower layers'
+    representation and restores lr.  Fixture generated by the unmodified reference."""
+    import os
+    fx = Fixture("pretrained_finetune_100_40_20.npz")
+    m = fx.meta
+    s = fx.stream()
+    sizes, JH, K, B, NB = m["sizes"], m["joint_hidden"], m["K"], m["B"], m["NB"]
+    X = (s.uniform((B * NB, 100)) > 0.75).astype(F32)
+    Y = np.eye(K, dtype=F32)[fx["yi"]]
+    dl = loader(X, Y, B)
+    mdl = iMDBN(sizes, JH, params=dict(m["params"]), dataloader=dl, val_loader=dl, device=torch.device(dev), num_labels=K)
+    before = [r.W.data_ptr() for r in mdl.image_idbn.layers]
+    for r in mdl.image_idbn.layers:                       # make the momentum buffers non-zero: loading must re-zero them
+        r.W_m = torch.ones_like(r.W.data)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_idbn_small.pkl")
+    assert mdl.load_pretrained_image_idbn(path) is True
+    assert not mdl.load_pretrained_image_idbn(path + ".missing")
+    for i, r in enumerate(mdl.image_idbn.layers):
+        assert r.W.data_ptr() != before[i] and r.W.device.type == torch.device(dev).type          # re-bound, on the device
+        assert float(r.W_m.abs().sum()) == 0.0 and float(r.hb_m.abs().sum()) == 0.0 and float(r.vb_m.abs().sum()) == 0.0
+        assert abs(float(r.W.detach().double().sum()) - float(fx[f"loaded{i}_W_sum"])) < 1e-6
+    last = mdl.image_idbn.layers[-1]
+    lr0 = float(last.lr)
+    assert abs(lr0 - m["lr0"]) < 1e-12
+    mdl.finetune_image_last_layer(epochs=0)               # no-op (imdbn.py:357-358)
+    with E.use_rng(E.ReplayRng(s)):
+        mdl.finetune_image_last_layer(epochs=m["epochs"], lr_scale=m["lr_scale"])
+    assert float(last.lr) == lr0                          # restored (imdbn.py:383)
+    losses = torch.cat(mdl.finetune_losses).numpy()
+    assert_close(losses, fx["losses"], 5e-5, "fine-tuning losses")
+    check_state(last, fx, "last_", rel)
+    check_state(mdl.image_idbn.layers[0], fx, "first_", 1e-7)
     return mdl
 
 

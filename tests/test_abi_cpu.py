@@ -38,7 +38,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(native.RbmDesc) == 8 * 7 + 4 * 4 + 4 * 8
     assert C.sizeof(native.Rng) == 8 + 8 * 3 + 8 * 4 + 8 * 3
     assert C.sizeof(native.ChainStep) == 24
-    assert C.sizeof(native.CdOpts) == 72            # 9 x 4 B + pad + next_data, ld_next, next_slot, data_slot, data_binary + pad
+    assert C.sizeof(native.CdOpts) == 72            # 9 x 4 B + pad + next_data, ld_next, next_slot, data_slot, data_binary, next_binary
 
 
 def test_no_gpu_call_reports_nodevice_as_exception():

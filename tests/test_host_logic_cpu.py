@@ -47,6 +47,10 @@ def test_bimodal_small_host_logic(tmp_path):
         assert torch.allclose(a.W.cpu(), b.W.detach().cpu(), rtol=0, atol=3e-4)
 
 
+def test_pretrained_finetune_host_logic():
+    P.case_pretrained_finetune("cpu", rel=5e-5)
+
+
 def test_live_best_of_k_host_logic():
     P.case_live_best_of_k("cpu")
 

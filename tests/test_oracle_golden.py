@@ -6,6 +6,8 @@ last ulp of exp(), so continuous outputs agree to ~1e-6 relative; sampled paths 
 exactly unless a Bernoulli margin |p-u| is below that noise (the fixtures record their
 minimum margin).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -189,12 +191,14 @@ def test_imdbn_small_train_joint_and_cross_reconstruct():
     for i, st in enumerate(layers):
         _check_state(st, fx, f"img{i}_", rel=5e-5)
     zcm = O.init_joint_bias_from_data(layers, joint, batches, K, n_batches=10)       # train_joint prologue
-    cd_losses, py_sums, img_sums = [], [], []
+    cd_losses, py_sums, img_sums, metrics = [], [], [], []
     for epoch in range(m["joint_epochs"]):
         ps = 0.0; isum = 0.0
+        tot = np.zeros(5, np.float64)                       # n, top1, top3, ce_sum, mse_sum  (imdbn.py:544-551)
         for b_idx, (img, y) in enumerate(batches):
             r = O.train_joint_batch(layers, joint, img, y, epoch, b_idx, s, p["JOINT_CD"],
                                     p["JOINT_AUX_COND_STEPS"], p["CROSS_GIBBS_STEPS"], z_class_mean=zcm)
+            tot += np.array([r["n"], r["top1"], r["top3"], r["ce_sum"], r["mse_sum"]], np.float64)
             if r["loss_cd"] is not None:
                 cd_losses.append(r["loss_cd"])
             ps += float(r["p_y"].astype(np.float64).sum()); isum += float(r["img_from_txt"].astype(np.float64).sum())
@@ -202,6 +206,12 @@ def test_imdbn_small_train_joint_and_cross_reconstruct():
                 assert_close(r["p_y"], fx[f"cross_py_e{epoch}_last"], 2e-4, f"p_y epoch {epoch}")
                 assert_close(r["img_from_txt"], fx[f"cross_img_e{epoch}_last"], 2e-4, f"img epoch {epoch}")
         py_sums.append(ps); img_sums.append(isum)
+        metrics.append([tot[1] / tot[0], tot[2] / tot[0], tot[3] / tot[0], tot[4] / (tot[0] * img.shape[1])])   # :648-657
+    # the reference's online metrics (recorded from its own F.binary_cross_entropy / F.mse_loss calls)
+    metrics = np.array(metrics)
+    np.testing.assert_allclose(metrics[:, :2], fx["joint_metrics"][:, :2], rtol=0, atol=1e-12, err_msg="top-1 / top-3")
+    assert_close(metrics[:, 2], fx["joint_metrics"][:, 2], 1e-5, "text CE per epoch")
+    assert_close(metrics[:, 3], fx["joint_metrics"][:, 3], 1e-5, "image MSE per epoch")
     assert_close(zcm, fx["z_class_mean"], 1e-5, "z_class_mean")
     assert_close(np.array(cd_losses, F32), fx["cd_losses"], 1e-4, "cd losses")
     assert_close(np.array(py_sums), fx["cross_py_sum_per_epoch"], 1e-5, "sum p_y per epoch")
@@ -290,3 +300,38 @@ def test_c2_headline_digest():
         assert_close(a.ravel()[fx[k + "_probe_idx"]], fx[k + "_probe_val"], 1e-4, k + " probes", atol=1e-6)
     for k in ("hid_bias", "vis_bias", "hb_m", "vb_m"):
         assert_close(getattr(st, k), fx[k], 1e-4, k, atol=1e-6)
+
+
+def test_pretrained_idbn_is_loaded_and_its_last_layer_fine_tuned():
+    """imdbn.py:294-384: the reference pickle's layers (dict form), momentum re-zeroed, 2 fine-tuning epochs of the last
+    layer at lr x 0.3 on the representation of the lower layers; the oracle replays the fixture's draws."""
+    import pickle
+    import imdbn.models  # noqa: F401  (the classes the reference pickle names)
+    fx = Fixture("pretrained_finetune_100_40_20.npz")
+    m = fx.meta
+    s = fx.stream()
+    B, NB = m["B"], m["NB"]
+    X = (s.uniform((B * NB, 100)) > 0.75).astype(F32)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_idbn_small.pkl"), "rb") as f:
+        obj = pickle.load(f)
+    p = m["params"]
+    layers = []
+    for i, r in enumerate(obj["layers"]):
+        st = O.RBMState.create(r.W.detach().cpu().numpy().astype(F32), p["LEARNING_RATE"], p["WEIGHT_PENALTY"], p["INIT_MOMENTUM"],
+                               dynamic_lr=True, final_momentum=p["FINAL_MOMENTUM"],
+                               sparsity=bool(r.sparsity), sparsity_factor=float(r.sparsity_factor),
+                               hid_bias=r.hid_bias.detach().cpu().numpy().astype(F32), vis_bias=r.vis_bias.detach().cpu().numpy().astype(F32))
+        assert abs(float(st.W.astype(np.float64).sum()) - float(fx[f"loaded{i}_W_sum"])) < 1e-9
+        layers.append(st)                                   # momentum buffers start at zero (imdbn.py:329-331)
+    last = layers[-1]
+    last.lr = max(1e-8, m["lr0"] * m["lr_scale"])           # :363
+    losses = []
+    for ep in range(m["epochs"]):
+        for b in range(NB):
+            v = X[b * B:(b + 1) * B]
+            for st in layers[:-1]:
+                v = O.forward(st, v)
+            losses.append(O.train_epoch(last, v, ep, p["CD"], s))
+    assert_close(np.array(losses, F32), fx["losses"], 1e-5, "fine-tuning losses")
+    _check_state(last, fx, "last_", rel=5e-5)
+    _check_state(layers[0], fx, "first_", rel=0.0)

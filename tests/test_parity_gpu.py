@@ -52,6 +52,19 @@ def test_imdbn_small_fixture_gpu():
     P.case_imdbn_small(DEV, rel=3e-4)
 
 
+def test_pretrained_finetune_fixture_gpu():
+    P.case_pretrained_finetune(DEV, rel=1e-4)
+
+
+def _mk_state(V, H, seed=0):
+    """The oracle state of _mk(V, H, None, seed) alone (no device object)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    W0 = (g.standard_normal((V, H), dtype=F32) / F32(np.sqrt(V))).astype(F32)
+    hb = (g.standard_normal(H, dtype=F32) * F32(0.1)).astype(F32)
+    vb = (g.standard_normal(V, dtype=F32) * F32(0.1)).astype(F32)
+    return O.RBMState.create(W0, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, hid_bias=hb, vis_bias=vb)
+
+
 def _mk(V, H, groups=None, seed=0, **kw):
     from imdbn.models import RBM
     g = np.random.Generator(np.random.PCG64(seed))
@@ -611,39 +624,57 @@ def test_factor_wire_form_round_trips_and_poisons_on_a_false_promise(binary, _na
         assert torch.isnan(rd.hid_bias.data).any()
 
 
-@pytest.mark.parametrize("V,H,B,rows", [(545, 380, 127, 24), (20, 468, 95, 24), (982, 24, 52, 28), (545, 64, 33, 20),
-                                        (5511, 64, 33, 0), (6301, 36, 20, 0), (4500, 40, 70, 0)])
-def test_fused_k2_row_tiles_that_do_not_end_on_16_columns(V, H, B, rows, _native):
-    """The fused K2 takes 20 / 24 / 28-row tiles for V in (4096, 7168] (rows = 0: the automatic choice; else forced):
-    its tiles must still write the operand form's padding columns [V, Vpad) -- two consecutive updates and a chain
-    (the second propagation reads what the first left) against the oracle.  Regression for a bug found by
-    tools/stress_parity.py (stale padding columns -> NaN)."""
+@pytest.mark.parametrize("V,H,B,rows,kernel", [
+    (545, 380, 127, 24, "old"), (20, 468, 95, 24, "old"), (982, 24, 52, 28, "old"), (545, 64, 33, 20, "old"),
+    (5511, 64, 33, 0, "old"), (6301, 36, 20, 0, "old"), (4500, 40, 70, 0, "old"),
+    (545, 380, 127, 40, "k2s"), (2000, 468, 95, 8, "k2s"), (982, 24, 52, 24, "k2s"), (5511, 64, 33, 48, "k2s"),
+    (6301, 36, 20, 0, "k2s"), (1201, 132, 70, 16, "k2s"), (4500, 40, 130, 32, "k2s")])
+def test_fused_k2_row_tiles_that_do_not_end_on_16_columns(V, H, B, rows, kernel, _native):
+    """Tile heights of the fused K2 kernels (rows = 0: the automatic choice; else forced), old = gemm_down_fused (20 / 24 /
+    28-row tiles for V in (4096, 7168]), k2s = k2_stream (8 .. 48 rows, one / two / three 16-row MFMA tiles): the tiles must
+    cover the operand forms' padding columns [V, Vpad) -- two consecutive updates and a chain (the second propagation reads
+    what the first left) against the oracle.  Regression for a bug found by tools/stress_parity.py (stale padding columns
+    -> NaN).  EVERY case compares: the Philox seed is the first one for which the oracle's smallest Bernoulli margin |p - u|
+    is above rounding level (1e-6; fp32 summation-order noise in p is ~1e-7), so no case silently degrades to a finiteness check."""
     from imdbn import engine as E
-    _native.set_option("down_rows", rows)
+    if kernel == "old":
+        _native.set_option("no_k2s", 1); _native.set_option("down_rows", rows)
+    else:
+        _native.set_option("k2s_rows", rows)
     try:
-        r, st, g = _mk(V, H, None, seed=V + H)
+        g0 = np.random.Generator(np.random.PCG64(V + H))
+        _, st0, g = _mk(V, H, None, seed=V + H)
         Xs = [(g.random((B, V), dtype=F32) > 0.6).astype(F32) for _ in range(2)]
+        vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+        vk[:, : V // 2] = Xs[0][:, : V // 2]; km[:, : V // 2] = 1
+        seed = want = None
+        for cand in range(3, 100):
+            st = _mk_state(V, H, seed=V + H)
+            O.reset_margin()
+            s = PhiloxStream(cand)
+            o0 = O.train_epoch(st, Xs[0], 1, 2, s); o1 = O.train_epoch(st, Xs[1], 1, 1, s)
+            oo = O.conditional_gibbs(st, vk, km, s, n_steps=2)
+            if O.BERNOULLI_MARGIN["min"] > 1e-6:
+                seed, want = cand, (o0, o1, oo, st)
+                break
+        assert seed is not None, "no Philox seed with a comfortable Bernoulli margin among 97 candidates"
+        o0, o1, oo, st = want
+        r, _, _ = _mk(V, H, None, seed=V + H)
         # poison the workspace first: stale contents must not matter
         ws = _native._workspace(torch.device(DEV), V, H, B)
         ws.view(torch.float32).fill_(float("nan"))
-        with E.use_rng(E.PhiloxRng(seed=3)):
+        with E.use_rng(E.PhiloxRng(seed=seed)):
             l0 = float(r.train_epoch(P.T(Xs[0], DEV), 1, 10, CD=2))
             l1 = float(r.train_epoch(P.T(Xs[1], DEV), 1, 10, CD=1))
-            vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
-            vk[:, : V // 2] = Xs[0][:, : V // 2]; km[:, : V // 2] = 1
             out = P.N(r.conditional_gibbs(P.T(vk, DEV), P.T(km, DEV), n_steps=2))
-        O.reset_margin()
-        s = PhiloxStream(3)
-        o0 = O.train_epoch(st, Xs[0], 1, 2, s); o1 = O.train_epoch(st, Xs[1], 1, 1, s)
-        oo = O.conditional_gibbs(st, vk, km, s, n_steps=2)
         assert np.isfinite([l0, l1]).all() and np.isfinite(out).all()
-        if O.BERNOULLI_MARGIN["min"] > 3e-6:          # otherwise a sample was decided at rounding level: only finiteness is checked
-            assert_close(np.array([l0, l1], F32), np.array([o0, o1], F32), 1e-5, "losses")
-            for k in P.KEYS:
-                assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
-            assert_close(out, oo, 1e-4, "chain", atol=2e-6)
+        assert_close(np.array([l0, l1], F32), np.array([o0, o1], F32), 1e-5, "losses")
+        for k in P.KEYS:
+            assert_close(P.N(getattr(r, k)), getattr(st, k), 1e-4, k, atol=2e-6)
+        assert_close(out, oo, 1e-4, "chain", atol=2e-6)
     finally:
-        _native.set_option("down_rows", 0)
+        for k in ("no_k2s", "down_rows", "k2s_rows"):
+            _native.set_option(k, 0)
 
 
 def test_idbn_train_lookahead_with_a_ragged_last_batch_equals_plain_loop(tmp_path):

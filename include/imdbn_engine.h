@@ -251,6 +251,24 @@ int imdbn_rbm_clamped_stats(const imdbn_rbm_desc* d, const float* v_known, const
                             const imdbn_cd_opts* o, imdbn_rng* rng, float* packed,
                             void* ws, size_t ws_bytes, imdbn_stream_t stream);
 
+/* ---- K3 alone: the weight / bias update of rbm.py:209-224 from caller-supplied phase tensors ---------------------
+ * W_m <- mom W_m + lr ((vpos^T hpos - vneg^T hneg)/B - wd W) ; W += W_m ; bias updates from the column sums (with the
+ * sparsity term of rbm.py:217-219 when o->sparsity).  fp32 [B][V] / [B][H] inputs; no loss is computed. */
+int imdbn_rbm_assoc_update(const imdbn_rbm_desc* d, const float* vpos, int64_t ldvp, const float* hpos, int64_t ldhp,
+                           const float* vneg, int64_t ldvn, const float* hneg, int64_t ldhn, int B, const imdbn_cd_opts* o,
+                           void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+/* ---- C1: the data-parallel exchange over RCCL (xGMI) for binders that do not use torch.distributed ---------------
+ * (the Python classes exchange through torch.distributed, whose "nccl" backend is the same RCCL).  One communicator
+ * per process and GPU: rank 0 calls imdbn_comm_unique_id (128 bytes), the caller carries the id to every rank, every
+ * rank calls imdbn_comm_init; then per CD step either imdbn_allreduce_sum_f32 on the packed statistics of
+ * imdbn_rbm_cd_stats, or imdbn_allgather_bytes on the factor blocks.  librccl is opened on first use. */
+int imdbn_comm_unique_id(void* id128);
+int imdbn_comm_init(void** comm, int world, int rank, const void* id128);
+int imdbn_comm_destroy(void* comm);
+int imdbn_allreduce_sum_f32(void* comm, float* buf, size_t count, imdbn_stream_t stream);
+int imdbn_allgather_bytes(void* comm, const void* send, void* recv, size_t bytes_per_rank, imdbn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <vector>
 
 #include "../../include/imdbn_engine.h"
@@ -399,17 +400,22 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         f.op.bits = want_hbits ? L.hid_bits : nullptr; f.op.bits_shape = 1; f.op.bits_cols = 32;
         if (f.op.rm == L.hid_rm) c.hid_bits_ok = want_hbits;
         if (want_hbits && !g_no_bits) f.op.rm = nullptr, f.rm_src = 0;      // the fused K2 reads the bit plane, nobody reads the bf16 form
-        const size_t lds = (size_t)4 * K1S_RING + (size_t)8 * a.kchunk + 16;
+        const size_t lds = (size_t)4 * K1S_RING + (size_t)8 * a.kchunk;      // 80 KB at the headline shape: two workgroups per CU
         static bool attr_done = false;
         if (!attr_done) {
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK + 16));
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK + 16));
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK));
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK));
             attr_done = true;
         }
         f.lean = lean_ok(f);
-        dim3 grid(L.k1s_tiles, a.ks, mb);
-        if (c.nw == 3) hipLaunchKernelGGL(k1_stream<3>, grid, dim3(256), lds, c.s, a, f);
-        else           hipLaunchKernelGGL(k1_stream<1>, grid, dim3(256), lds, c.s, a, f);
+        // + block rows that prepare the next batch (one 64-column item each, or a few)
+        PrepArgs pz;
+        memset(&pz, 0, sizeof(pz));
+        const int items = next ? cdiv(std::max(next->N, next->op.ldrm), 64) : 0;
+        const int pr = next ? std::min(8, cdiv(items, L.k1s_tiles)) : 0;
+        dim3 grid(L.k1s_tiles, a.ks + pr, mb);
+        if (c.nw == 3) hipLaunchKernelGGL(k1_stream<3>, grid, dim3(256), lds, c.s, a, f, next ? *next : pz);
+        else           hipLaunchKernelGGL(k1_stream<1>, grid, dim3(256), lds, c.s, a, f, next ? *next : pz);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -445,21 +451,18 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
             f.dbg = g_dbg;
             if (f.op.bits && (f.n_groups > 0 || f.vmode == 0)) f.op.bits = nullptr;      // not a pure 0/1 sample
             f.lean = lean_ok(f);
+            if (next) return fail(IMDBN_E_INVALID, "internal: k2_stream carries no next-batch blocks");
             const int nsteps = cdiv(L.H, 32);
-            size_t lds = (size_t)((nsteps * 256 + 255) & ~255) + (size_t)4 * 16 * MT * K2S_LDR * 4;
-            if (next) lds = std::max(lds, (size_t)3 * 4 * 64 * 16 * 2);      // prep_item_body's stage
-            PrepArgs pz;
-            memset(&pz, 0, sizeof(pz));
-            dim3 grid(nbx + (next ? cdiv(std::max(next->N, next->op.ldrm), 64) : 0), 1, mb);
+            const size_t lds = (size_t)((nsteps * 256 + 255) & ~255) + (size_t)std::max(K2S_LW * 16 * MT * K2S_LDR * 4, 64);
+            dim3 grid(nbx, 1, mb);
             hipError_t le = hipSuccess;
-#define LAUNCH_K2S(NW, MTV, NX) do { \
+#define LAUNCH_K2S(NW, MTV) do { \
         static bool attr = false; \
-        if (!attr) { le = hipFuncSetAttribute((const void*)k2_stream<NW, MTV, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        if (le == hipSuccess) hipLaunchKernelGGL((k2_stream<NW, MTV, NX>), grid, dim3(256), lds, c.s, a, f, next ? *next : pz, nbx); } while (0)
-#define LAUNCH_K2S_M(NW, NX) do { if (MT == 1) LAUNCH_K2S(NW, 1, NX); else if (MT == 2) LAUNCH_K2S(NW, 2, NX); else LAUNCH_K2S(NW, 3, NX); } while (0)
+        if (!attr) { le = hipFuncSetAttribute((const void*)k2_stream<NW, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        if (le == hipSuccess) hipLaunchKernelGGL((k2_stream<NW, MTV>), grid, dim3(64 * K2S_W), lds, c.s, a, f); } while (0)
+#define LAUNCH_K2S_M(NW) do { if (MT == 1) LAUNCH_K2S(NW, 1); else if (MT == 2) LAUNCH_K2S(NW, 2); else LAUNCH_K2S(NW, 3); } while (0)
             if (lds > 160 * 1024) return fail(IMDBN_E_UNSUPPORTED, "internal: k2_stream LDS");
-            // one instantiation per (terms, tiles): without a next batch the launch simply has no blocks past main_nbx
-            if (c.nw == 3) LAUNCH_K2S_M(3, true); else LAUNCH_K2S_M(1, true);
+            if (c.nw == 3) LAUNCH_K2S_M(3); else LAUNCH_K2S_M(1);
 #undef LAUNCH_K2S_M
 #undef LAUNCH_K2S
             HIPCHK(le);
@@ -638,6 +641,9 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
     // the visible sample of the negative phase leaves the fused K2 as a bit plane too when its tiles are whole bytes wide
     const bool vbits = c.d->n_groups == 0 && (k2s_for_cd(c.d) || L.down_tr % 8 == 0);
     const bool k1s_neg = vec4_weights(c.d) && !g_no_k1s && L.Vpad > 1024;      // the negative-phase K1 will be k1_stream (prop())
+    // the next batch's preparation rides on the old fused K2 (gemm_down_fused_next) or, with k2_stream (a 512-thread block per
+    // CU: nothing fits beside it), on the negative-phase k1_stream
+    const bool next_on_k1 = next && k2s_for_cd(c.d) && vbits && k1s_neg;
     // positive phase: P+ = up(data); h = 1[P+ > U]
     {
         FinishArgs f = new_finish();
@@ -662,7 +668,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
             f.colsum_part = L.cs_vneg; f.colsum_src = 2;
             f.loss_ref = data; f.ld_ref = ldd; f.loss_src = 1; f.loss_part = L.loss_part;
             if (vbits) f.op.bits = L.vis_bits[1];
-            CHK(prop(c, false, OpIn{L.hid_rm, 1, nullptr}, f, it == 0 ? next : nullptr));
+            CHK(prop(c, false, OpIn{L.hid_rm, 1, nullptr}, f, (it == 0 && !next_on_k1) ? next : nullptr));
         }
         {   // h_prob = up(v); h = 1[h_prob > U]  (the last draw is consumed but unused, rbm.py:208)
             FinishArgs f = new_finish();
@@ -670,7 +676,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
             if (!last) { f.vmode = 1; f.uni = u; f.op.rm = L.hid_rm; f.op.rm_terms = 1; f.rm_src = 2; }
             f.op.tr = L.hid_tr[1]; f.op.tr_terms = c.ht; f.tr_src = 1; f.op.tr_negate = 1;
             f.colsum_part = L.cs_hneg; f.colsum_src = 1;
-            CHK(prop(c, true, OpIn{L.vis_rm[1], 1, nullptr, vbits ? L.vis_bits[1] : nullptr, 1}, f));
+            CHK(prop(c, true, OpIn{L.vis_rm[1], 1, nullptr, vbits ? L.vis_bits[1] : nullptr, 1}, f, (it == 0 && next_on_k1) ? next : nullptr));
         }
     }
     return 0;
@@ -1050,8 +1056,17 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
             pn.op.rm = nullptr; pn.op.rm_terms = 0; pn.op.tr_terms = 1;
         }
     }
+    // Where the next batch is prepared: as extra blocks of the fused K2 (gemm_down_fused_next) or of the negative-phase
+    // k1_stream (cd_phases decides); where neither can carry them, a prep_operand launch of its own, first thing.
+    const Layout& L0 = c.L;
+    const bool rides = next_rows > 0 && (!k2s_for_cd(d) || (d->n_groups == 0 && vec4_weights(d) && !g_no_k1s && L0.Vpad > 1024));
+    if (next_rows > 0 && !rides) {
+        pn.zero = nullptr; pn.n_zero = 0;
+        hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(pn.N, pn.op.ldrm), 64), c.L.P), dim3(256), 0, c.s, pn);
+        HIPCHK(hipGetLastError());
+    }
     if (o->data_slot) { use_slot(c.L, o->data_slot); c.data_prepped = true; }
-    CHK(cd_phases(c, data, ldd, o, next_rows > 0 ? &pn : nullptr));
+    CHK(cd_phases(c, data, ldd, o, rides ? &pn : nullptr));
     CHK(c.rng.finish());
     const BiasArgs bias = make_bias(c, o, o->sparsity != 0, (float)B, loss_out);
     CHK(launch_assoc(c, 0, o, c.nw == 1 ? 1 : 0, c.L.flags, 1, (float)B, nullptr, &bias));
@@ -1369,6 +1384,111 @@ int imdbn_rbm_clamped_stats(const imdbn_rbm_desc* d, const float* v_known, const
     CHK(launch_assoc(c, 1, o, c.rt, nullptr, o->sample_v ? 1 : c.rt, 1.0f, packed));
     CHK(launch_pack(c, packed));
     return 0;
+}
+
+
+// ---- K3 alone: rbm.py:209-224 from caller-supplied phase tensors ------------------------------------------------------
+int imdbn_rbm_assoc_update(const imdbn_rbm_desc* d, const float* vpos, int64_t ldvp, const float* hpos, int64_t ldhp,
+                           const float* vneg, int64_t ldvn, const float* hneg, int64_t ldhn, int B, const imdbn_cd_opts* o,
+                           void* ws, size_t ws_bytes, imdbn_stream_t stream) {
+    CHK(check_desc(d, true));
+    if (!vpos || !hpos || !vneg || !hneg || !o || ldvp < d->V || ldvn < d->V || ldhp < d->H || ldhn < d->H)
+        return fail(IMDBN_E_INVALID, "assoc_update: bad tensor argument");
+    Ctx c(d, nullptr, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    const Layout& L = c.L;
+    // operand planes + column sums of the four tensors (exact three-term planes wherever a value is not exactly bf16)
+    CHK(prep(c, vpos, ldvp, L.V, nullptr, L.Vpad, L.vis_tr[0], L.flags, L.cs_vpos, c.rt));
+    CHK(prep(c, vneg, ldvn, L.V, nullptr, L.Vpad, L.vis_tr[1], nullptr, L.cs_vneg, c.rt));
+    CHK(prep(c, hpos, ldhp, L.H, nullptr, L.Hpad, L.hid_tr[0], L.flags_h, L.cs_hpos, c.ht));
+    {
+        PrepArgs p;
+        memset(&p, 0, sizeof(p));
+        p.in = hneg; p.ld = ldhn; p.B = L.B; p.Bp = L.Bp; p.N = L.H;
+        p.op.ldrm = L.Hpad; p.op.Bp = L.Bp; p.op.tr = L.hid_tr[1]; p.op.tr_ts = (int64_t)L.H * L.Bp; p.op.tr_terms = c.ht; p.op.tr_negate = 1;
+        p.colsum_part = L.cs_hneg;
+        hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Hpad, 64), L.P), dim3(256), 0, c.s, p);
+        HIPCHK(hipGetLastError());
+    }
+    BiasArgs bias = make_bias(c, o, o->sparsity != 0, (float)B, nullptr);
+    bias.loss_part = nullptr; bias.n_loss = 0;
+    CHK(launch_assoc(c, 0, o, c.nw == 1 ? 1 : 0, L.flags, c.rt, (float)B, nullptr, &bias));
+    return 0;
+}
+
+// ---- C1: collectives over RCCL for callers that do not go through torch.distributed ------------------------------------
+// librccl is opened on first use (dlopen: the engine has no link-time dependency on it; a process that already runs
+// torch.distributed's nccl backend gets that same library).  One communicator per (process, GPU); the caller moves the
+// 128-byte unique id from rank 0 to the other ranks by whatever channel it has.
+namespace {
+struct Id128 { char b[128]; };      // ncclUniqueId, passed by value
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+} g_rccl;
+
+int rccl_load() {
+    if (g_rccl.h) return 0;
+    void* h = nullptr;
+    for (const char* nm : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(IMDBN_E_UNSUPPORTED, "librccl not found: %s", dlerror());
+    auto sym = [&](const char* n) { return dlsym(h, n); };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.AllGather)
+        return fail(IMDBN_E_UNSUPPORTED, "librccl lacks an expected symbol");
+    g_rccl.h = h;
+    return 0;
+}
+int rccl_fail(int rc, const char* what) {
+    return fail(rc > 0 ? rc : IMDBN_E_INVALID, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+}
+}  // namespace
+
+int imdbn_comm_unique_id(void* id128) {
+    if (!id128) return fail(IMDBN_E_INVALID, "comm_unique_id: null buffer");
+    CHK(rccl_load());
+    const int rc = g_rccl.GetUniqueId(id128);
+    return rc ? rccl_fail(rc, "ncclGetUniqueId") : 0;
+}
+
+int imdbn_comm_init(void** comm, int world, int rank, const void* id128) {
+    if (!comm || !id128 || world < 1 || rank < 0 || rank >= world) return fail(IMDBN_E_INVALID, "comm_init: bad argument");
+    CHK(rccl_load());
+    Id128 id;
+    memcpy(id.b, id128, 128);
+    const int rc = g_rccl.CommInitRank(comm, world, id, rank);
+    return rc ? rccl_fail(rc, "ncclCommInitRank") : 0;
+}
+
+int imdbn_comm_destroy(void* comm) {
+    if (!comm) return 0;
+    CHK(rccl_load());
+    const int rc = g_rccl.CommDestroy(comm);
+    return rc ? rccl_fail(rc, "ncclCommDestroy") : 0;
+}
+
+int imdbn_allreduce_sum_f32(void* comm, float* buf, size_t count, imdbn_stream_t stream) {
+    if (!comm || !buf) return fail(IMDBN_E_INVALID, "allreduce: bad argument");
+    CHK(rccl_load());
+    const int rc = g_rccl.AllReduce(buf, buf, count, /* ncclFloat32 */ 7, /* ncclSum */ 0, comm, S(stream));
+    return rc ? rccl_fail(rc, "ncclAllReduce") : 0;
+}
+
+int imdbn_allgather_bytes(void* comm, const void* send, void* recv, size_t bytes_per_rank, imdbn_stream_t stream) {
+    if (!comm || !send || !recv) return fail(IMDBN_E_INVALID, "allgather: bad argument");
+    CHK(rccl_load());
+    const int rc = g_rccl.AllGather(send, recv, bytes_per_rank, /* ncclUint8 */ 1, comm, S(stream));
+    return rc ? rccl_fail(rc, "ncclAllGather") : 0;
 }
 
 }  // extern "C"

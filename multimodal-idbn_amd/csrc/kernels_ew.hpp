@@ -646,13 +646,18 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
 // third resident block per CU of the fused K2 (read-only stream, 23 us) the same work is done a few us into the launch.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ void prep_item_body(const PrepArgs& a, int tx, int mb, bf16_t* rmst) {
+// the 16 values of this thread (column c of tile tx, rows 16 kq .. + 15 of chunk mb): requested here, used by prep_item_process
+__device__ __forceinline__ void prep_item_load(const PrepArgs& a, int tx, int mb, float (&v)[16]) {
     const int c = threadIdx.x & 63, kq = threadIdx.x >> 6;
-    const int ntx = (max(a.N, a.op.ldrm) + 63) / 64;
-    const int col = tx * 64 + c, cc = min(col, a.N - 1);
-    float v[16];
+    const int cc = min(tx * 64 + c, a.N - 1);
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = a.in[(int64_t)min(mb * 64 + 16 * kq + i, a.B - 1) * a.ld + cc];
+}
+
+__device__ __forceinline__ void prep_item_process(const PrepArgs& a, int tx, int mb, const float (&v)[16], bf16_t* rmst) {
+    const int c = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int ntx = (max(a.N, a.op.ldrm) + 63) / 64;
+    const int col = tx * 64 + c;
     const RmStage stg{rmst, 4, 64, tx * 64, mb * 64};
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -673,8 +678,16 @@ __device__ __forceinline__ void prep_item_body(const PrepArgs& a, int tx, int mb
         if (a.flag && c == 0) a.flag[by * ntx + tx] = (any ? FLAG_INEXACT : 0) | (anyb ? FLAG_NONBINARY : 0);
         if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)by * a.N + col] = csum;
     }
-    lds_barrier();
-    flush_rm_stage(a.op, stg);
+    if (a.op.rm) {                    // the K16-blocked form leaves through the LDS stage (block-uniform)
+        lds_barrier();
+        flush_rm_stage(a.op, stg);
+    }
+}
+
+__device__ __forceinline__ void prep_item_body(const PrepArgs& a, int tx, int mb, bf16_t* rmst) {
+    float v[16];
+    prep_item_load(a, tx, mb, v);
+    prep_item_process(a, tx, mb, v, rmst);
 }
 
 // Free energy of visible configurations (imdbn/utils/energy_utils.py:19-28):

@@ -938,6 +938,8 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
                         *reinterpret_cast<float4*>(a.Wm + idx) = m;
                         if constexpr (PASS == 0 || PASS == 3)
                             *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
+                        // (non-temporal stores were tried here in round 2: 51.3 us against 49.4 event-timed -- the tail of this kernel is
+                        //  not dirty lines lingering in L2)
                     } else {
                         float4 o = d;
                         if constexpr (PASS >= 2) { const float4 p = mc[reg]; o = make_float4(p.x + d.x, p.y + d.y, p.z + d.z, p.w + d.w); }
@@ -1241,6 +1243,10 @@ template <int MODE, int HT, int PASS>
 __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesArgs a, int tiles_per_block,
                                                               const BiasArgs bias, int bias_rows) {
     __shared__ __attribute__((aligned(16))) char smem[K3_LDS_BYTES];      // 160 KB static: all of the CU's LDS
+    // (Round 2 tried again to let the next batch's preparation ride here, on the CUs this ~one-block-per-CU grid leaves idle,
+    //  now with the slim output set of a 0/1 batch (0.5 MB of stores instead of 7.7 MB) and with three items of loads in flight
+    //  per worker: 68 us and 92 us for this kernel instead of 45.6.  Under this kernel's read + write stream nothing else makes
+    //  progress; the preparation rides on a read-only stream instead: k1_stream's negative-phase launch.)
     // The last `bias_rows` block rows of the grid do the (tiny, independent) bias / loss update of
     // rbm.py:216-226 instead of a dependent launch of their own: they only touch the bias vectors.
     if (bias_rows > 0 && (int)blockIdx.y >= (int)gridDim.y - bias_rows) {

@@ -39,9 +39,23 @@ struct K1sArgs {
     int kchunk, ks;                               // rows per K slice (multiple of 64), number of slices
 };
 
+// `next` / block rows >= a.ks: the launch can carry the preparation of the NEXT batch of the training loop (prep_item_body:
+// imdbn_cd_opts.next_data) as extra workgroups.  This kernel is a read-only stream with one workgroup per CU, 131 registers
+// and exactly half of a CU's LDS (64 KB of rings + 16 KB of bits at the headline shape): a second workgroup fits beside each
+// streaming one, so the extra blocks start at once and are gone a few us into the launch.  (The update kernel's idle CUs were
+// tried first: under its read + write stream the same work took 25-45 us longer than the kernel itself.)
 template <int NW>
-__global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const FinishArgs fa) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 rings][activation bits][1 int]; no static LDS (keeps the base 16-B aligned)
+__global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const FinishArgs fa, const PrepArgs next) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 rings][activation bits]; no static LDS (keeps the base 16-B aligned)
+    if ((int)blockIdx.y >= a.ks) {
+        const int nworkers = (gridDim.y - a.ks) * gridDim.x, wid = (blockIdx.y - a.ks) * gridDim.x + blockIdx.x;
+        const int ntx = (max(next.N, next.op.ldrm) + 63) / 64;
+        for (int it = wid; it < ntx; it += nworkers) {
+            prep_item_body(next, it, blockIdx.z, reinterpret_cast<bf16_t*>(smem));
+            if (next.op.rm) lds_barrier();
+        }
+        return;
+    }
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 31, kg = l >> 5;      // w: provably wave-uniform (scalar branches)
     const int tile = blockIdx.x, sl = blockIdx.y, z = blockIdx.z, ntiles = gridDim.x;
     const int n0 = tile * 32, mb = z * 64;
@@ -151,11 +165,15 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
         xs[i] = ((red[o] + red[2048 + o]) + red[2 * 2048 + o]) + red[3 * 2048 + o];
     }
     // caller data that were promised to be 0/1 and are not: the bit plane does not describe them -> NaN, loudly
+    int* s_words = reinterpret_cast<int*>(smem + 2 * K1S_RING);        // scratch words behind red[] (the rings are free now)
     if (a.aflag) {
         int bad = 0;
         const int cb0 = k0 / 64, cb1 = min((k_end + 63) / 64, a.ncb), wd = cb1 - cb0;
         for (int i = tid; i < wd * 8; i += 256) bad |= a.aflag[(z * 8 + i / wd) * a.ncb + cb0 + (i % wd)] & FLAG_NONBINARY;
-        if (__syncthreads_or(bad)) {
+        if (l == 0) s_words[4 + w] = 0;
+        if (__any(bad) && l == 0) s_words[4 + w] = 1;
+        __syncthreads();
+        if (s_words[4] | s_words[5] | s_words[6] | s_words[7]) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) xs[i] = __uint_as_float(0x7FC00000u);
         }
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the barrier, the counter add comes after it
         __syncthreads();
         int* cnt = a.counters + z * ntiles + tile;
-        int* s_last = reinterpret_cast<int*>(smem + 4 * K1S_RING + 8 * a.kchunk);
+        int* s_last = s_words;
         if (tid == 0) *s_last = (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ks - 1) ? 1 : 0;
         __syncthreads();
         stamp(st, sblk, 4);
@@ -222,7 +240,10 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int K2S_D = 3;                          // register ring depth (K32 steps) per wave
-constexpr int K2S_LDR = 68;                       // row pitch (floats) of the reduction buffer red[4][48][K2S_LDR]
+constexpr int K2S_W = 8;                          // waves per block: the 40 x 8 (column, row octet) items of the epilogue are ONE pass (5 waves)
+                                                  // instead of two (with 4 waves the second pass cost 2.5 us)
+constexpr int K2S_LW = 4;                         // waves that stream weights (one per SIMD; with all 8 the K loop ended 1.1 us later)
+constexpr int K2S_LDR = 68;                       // row pitch (floats) of the reduction buffer red[K2S_W][16 MT][K2S_LDR]
 
 struct K2sArgs {
     const float* W; int64_t ldw; int K, N;        // W[N][ldw]: N rows (visible units), K valid columns (hidden units), K % 4 == 0
@@ -233,20 +254,22 @@ struct K2sArgs {
 template <int MT>
 struct K2sOps { float4 w[MT][2]; };
 
-template <int NW, int MT, bool NEXT>
-__device__ __forceinline__ void k2s_body(const K2sArgs& a, const FinishArgs& fa, char* smem, int bx, int bz, int nbx) {
+template <int NW, int MT>
+__global__ __launch_bounds__(64 * K2S_W, 2) void k2_stream(const K2sArgs a, const FinishArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bx = blockIdx.x, bz = blockIdx.z, nbx = gridDim.x;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, m = l & 15, kg = l >> 4;
     const int TR = a.TR, v0 = bx * TR, mb = bz * 64;
-    const int nsteps = (a.K + 31) / 32;                       // K32 steps; wave w takes steps w, w + 4, ...
-    const int my = (nsteps - w + 3) / 4;
+    const int nsteps = (a.K + 31) / 32;                       // K32 steps; wave w takes steps w, w + K2S_W, ...
+    const int my = w < K2S_LW ? (nsteps - w + K2S_LW - 1) / K2S_LW : 0;
     uint8_t* hbl = reinterpret_cast<uint8_t*>(smem);          // [nsteps * 4][64] activation bytes of this batch chunk
-    float* red = reinterpret_cast<float*>(smem + ((nsteps * 4 * 64 + 255) & ~255));      // [4][16 MT][K2S_LDR]
+    float* red = reinterpret_cast<float*>(smem + ((nsteps * 4 * 64 + 255) & ~255));      // [K2S_LW][16 MT][K2S_LDR]
 
     // ---- hidden bits -> LDS: 16-B pieces, plain loads (12 KB at K = 1500)
     {
         const int n16 = nsteps * 4 * 4;                       // 16-B pieces: byte-row r, quarter q
         const int last_row = (a.K + 63) / 64 * 8 - 1;
-        for (int i = tid; i < n16; i += 256) {
+        for (int i = tid; i < n16; i += 64 * K2S_W) {
             const int r = i >> 2, q = i & 3;
             *reinterpret_cast<uint4*>(hbl + r * 64 + 16 * q) =
                 *reinterpret_cast<const uint4*>(a.abits + (int64_t)min(r, last_row) * a.Bp + mb + 16 * q);
@@ -258,7 +281,7 @@ __device__ __forceinline__ void k2s_body(const K2sArgs& a, const FinishArgs& fa,
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) wrow[mt] = a.W + (int64_t)min(v0 + 16 * mt + m, vlast) * a.ldw;
     auto load = [&](K2sOps<MT>& o, int i) {                   // wave-local step i
-        const int k0 = 32 * (4 * max(min(i, my - 1), 0) + w) + 8 * kg;
+        const int k0 = 32 * (K2S_LW * max(min(i, my - 1), 0) + (w & (K2S_LW - 1))) + 8 * kg;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             o.w[mt][0] = *reinterpret_cast<const float4*>(wrow[mt] + min(k0, a.K - 4));
@@ -271,7 +294,7 @@ __device__ __forceinline__ void k2s_body(const K2sArgs& a, const FinishArgs& fa,
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](const K2sOps<MT>& o, int i) {
-        const int step = 4 * i + w;
+        const int step = K2S_LW * i + w;
         uint4 bf[4];                                          // batch fragments: k = 32 step + 8 kg + j of batch row 16 nt + m
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) bf[nt] = bits_to_frag(hbl[(4 * step + kg) * 64 + 16 * nt + m]);
@@ -291,21 +314,21 @@ __device__ __forceinline__ void k2s_body(const K2sArgs& a, const FinishArgs& fa,
     const bool st = (fa.dbg & 128) != 0;
     const int sblk = bz * nbx + bx;
     stamp(st, sblk, 0);
-    // epilogue side inputs of pass A (columns 0..31 of the tile): requested before the K loop
-    const int cA = tid & 31, octA = tid >> 5;
-    const int ecolA = (cA < TR) ? v0 + cA : (1 << 30);
-    SideIn<8> sideA;
-    SideLean slA, slB;
-    const int cB = 32 + (tid & 15), octB = tid >> 4;          // pass B: waves 0, 1
-    const int ecolB = (cB < TR) ? v0 + cB : (1 << 30);
-    if (fa.lean) {
-        load_side_lean(fa, ecolA, mb + 8 * octA, slA);
-        if (MT == 3 && TR > 32 && w < 2) load_side_lean(fa, ecolB, mb + 8 * octB, slB);
-    } else {
-        load_side<8>(fa, ecolA, mb + 8 * octA, sideA);
+    // epilogue item of this thread: pass A = columns 0 .. 31 (waves 0-3: lanes = 32 columns x 2 row octets), pass B = columns
+    // 32 .. 47 (waves 4, 5: 16 columns x 4 octets); waves 6, 7 have none.  Side inputs are requested before the K loop.
+    const bool isA = w < 4, isB = MT == 3 && TR > 32 && (w == 4 || w == 5);
+    const int ec = isA ? (tid & 31) : 32 + (tid & 15), eoct = isA ? (tid >> 5) : ((tid - 256) >> 4);
+    const int ecol = (ec < TR) ? v0 + ec : (1 << 30);
+    SideIn<8> side;
+    SideLean sl;
+    if (isA || isB) {
+        if (fa.lean) load_side_lean(fa, ecol, mb + 8 * eoct, sl);
+        else         load_side<8>(fa, ecol, mb + 8 * eoct, side);
     }
+    if (w < K2S_LW) {
 #pragma unroll
-    for (int d = 0; d < K2S_D; ++d) load(ring[d], d);
+        for (int d = 0; d < K2S_D; ++d) load(ring[d], d);
+    }
     __syncthreads();                                          // the activation bytes are in LDS
     stamp(st, sblk, 1);
     for (int g = 0; g * K2S_D < my; ++g) {
@@ -320,37 +343,30 @@ __device__ __forceinline__ void k2s_body(const K2sArgs& a, const FinishArgs& fa,
     }
     stamp(st, sblk, 2);
     // ---- cross-wave reduction: C tile (mt, nt): lane holds batch row 16 nt + m, weight rows 16 mt + 4 kg + reg
+    if (w < K2S_LW) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) red[(w * 16 * MT + 16 * mt + 4 * kg + reg) * K2S_LDR + 16 * nt + m] = acc[mt][nt][reg];
+                for (int reg = 0; reg < 4; ++reg) red[(w * 16 * MT + 16 * mt + 4 * kg + reg) * K2S_LDR + 16 * nt + m] = acc[mt][nt][reg];
+    }
     __syncthreads();
     stamp(st, sblk, 3);
     float lsum = 0.f;
-    // pass A: columns 0 .. 31 (lanes = 32 columns x 2 row octets); pass B: columns 32 .. 47 (16 columns x 4 octets, waves 0, 1)
-    {
+    if (isA || isB) {                                         // wave-uniform
         float xs[8];
-        const float* p = red + cA * K2S_LDR + 8 * octA;
+        const float* p = red + ec * K2S_LDR + 8 * eoct;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            xs[i] = ((p[i] + p[16 * MT * K2S_LDR + i]) + p[2 * 16 * MT * K2S_LDR + i]) + p[3 * 16 * MT * K2S_LDR + i];
-        if (fa.lean) lsum += finish_lean8(fa, ecolA, mb + 8 * octA, xs, (mb >> 3) + octA, slA, 1, min(TR, 32));
-        else         lsum += finish_rows8(fa, ecolA, mb + 8 * octA, xs, (mb >> 3) + octA, sideA, nullptr, 1, min(TR, 32));
-    }
-    if constexpr (MT == 3) {
-        if (TR > 32 && w < 2) {                               // wave-uniform
-            SideIn<8> sideB;
-            if (!fa.lean) load_side<8>(fa, ecolB, mb + 8 * octB, sideB);
-            float xs[8];
-            const float* p = red + cB * K2S_LDR + 8 * octB;
+        for (int i = 0; i < 8; ++i) {
+            float t = p[i];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                xs[i] = ((p[i] + p[16 * MT * K2S_LDR + i]) + p[2 * 16 * MT * K2S_LDR + i]) + p[3 * 16 * MT * K2S_LDR + i];
-            if (fa.lean) lsum += finish_lean8(fa, ecolB, mb + 8 * octB, xs, (mb >> 3) + octB, slB, 2, TR - 32);
-            else         lsum += finish_rows8(fa, ecolB, mb + 8 * octB, xs, (mb >> 3) + octB, sideB, nullptr, 2, TR - 32);
+            for (int ww = 1; ww < K2S_LW; ++ww) t += p[ww * 16 * MT * K2S_LDR + i];      // fixed order
+            xs[i] = t;
         }
+        const int bshape = isA ? 1 : 2, bcols = isA ? min(TR, 32) : TR - 32;
+        if (fa.lean) lsum = finish_lean8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, sl, bshape, bcols);
+        else         lsum = finish_rows8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, side, nullptr, bshape, bcols);
     }
     stamp(st, sblk, 4);
     if (fa.loss_part) {
@@ -358,23 +374,14 @@ __device__ __forceinline__ void k2s_body(const K2sArgs& a, const FinishArgs& fa,
         const float t = wave_sum(lsum);
         if (l == 0) red[w] = t;
         __syncthreads();
-        if (tid == 0) fa.loss_part[bz * nbx + bx] = ((red[0] + red[1]) + red[2]) + red[3];
-    }
-    stamp(st, sblk, 5);
-}
-
-// NEXT: the launch carries the preparation of the following batch as extra blocks behind its `main_nbx` weight tiles
-// (prep_item_body: operand forms, bit plane, exactness map, column sums of imdbn_cd_opts.next_data)
-template <int NW, int MT, bool NEXT>
-__global__ __launch_bounds__(256, 2) void k2_stream(const K2sArgs a, const FinishArgs fa, const PrepArgs next, int main_nbx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if constexpr (NEXT) {
-        if ((int)blockIdx.x >= main_nbx) {
-            prep_item_body(next, blockIdx.x - main_nbx, blockIdx.z, reinterpret_cast<bf16_t*>(smem));
-            return;
+        if (tid == 0) {
+            float t2 = red[0];
+#pragma unroll
+            for (int ww = 1; ww < K2S_W; ++ww) t2 += red[ww];
+            fa.loss_part[bz * nbx + bx] = t2;
         }
     }
-    k2s_body<NW, MT, NEXT>(a, fa, smem, blockIdx.x, blockIdx.z, main_nbx);
+    stamp(st, sblk, 5);
 }
 
 }  // namespace imdbn

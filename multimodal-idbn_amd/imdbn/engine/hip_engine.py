@@ -81,7 +81,8 @@ class HipEngine:
         return ws[off.value:off.value + nbytes]
 
     def _workspace(self, dev, V, H, B):
-        key = (dev, V, H, B)
+        # one workspace per (device, shape, STREAM): two same-shape RBMs driven from two streams must not share scratch
+        key = (dev, V, H, B, torch.cuda.current_stream(dev).cuda_stream if torch.device(dev).type == "cuda" else 0)
         ws = self._ws.get(key)
         need = int(self._lib.imdbn_ws_bytes(V, H, B))
         if ws is None or ws.numel() < need:
@@ -303,7 +304,7 @@ class HipEngine:
         r, keep = self._rng(rng, sched, B, dev)
         loss = torch.empty(1, device=dev)
         ws = self._workspace(dev, d.V, d.H, B)
-        key = (dev, d.V, d.H, B)
+        key = (dev, d.V, d.H, B, torch.cuda.current_stream(dev).cuda_stream)
         st = self._pf.pop(key, None)
         if st is not None and st[0] == self._ident(x):
             o.data_slot = st[1]
@@ -319,6 +320,42 @@ class HipEngine:
         if nxt is not None:                      # the strong reference keeps the address from being recycled
             self._pf[key] = (self._ident(nxt), int(o.next_slot), nxt)
         return loss.reshape(())
+
+    def assoc_update(self, rbm, vpos, hpos, vneg, hneg, lr, mom):
+        """The weight / bias update alone (rbm.py:209-224) from the four phase tensors (imdbn_rbm_assoc_update)."""
+        d = self._desc(rbm, True)
+        ts = [_f32c(t, "t") for t in (vpos, hpos, vneg, hneg)]
+        B, dev = ts[0].size(0), ts[0].device
+        o = self._opts(rbm, lr, mom, 1, sparsity=getattr(rbm, "sparsity", False))
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_assoc_update(C.byref(d), _ptr(ts[0]), ts[0].stride(0), _ptr(ts[1]), ts[1].stride(0), _ptr(ts[2]),
+                                                  ts[2].stride(0), _ptr(ts[3]), ts[3].stride(0), B, C.byref(o), _ptr(ws), ws.numel(),
+                                                  self._stream(dev)), "imdbn_rbm_assoc_update")
+
+    # ---- RCCL through the C ABI (a binder without torch.distributed; the classes use torch.distributed) ---------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        N.check(self._lib.imdbn_comm_unique_id(buf), "imdbn_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, world: int, rank: int, uid: bytes):
+        comm = C.c_void_p(0)
+        N.check(self._lib.imdbn_comm_init(C.byref(comm), int(world), int(rank), C.create_string_buffer(uid, 128)), "imdbn_comm_init")
+        return comm
+
+    def comm_destroy(self, comm):
+        N.check(self._lib.imdbn_comm_destroy(comm), "imdbn_comm_destroy")
+
+    def comm_allreduce_sum(self, comm, t: torch.Tensor):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        N.check(self._lib.imdbn_allreduce_sum_f32(comm, _ptr(t), t.numel(), self._stream(t.device)), "imdbn_allreduce_sum_f32")
+        return t
+
+    def comm_allgather(self, comm, send: torch.Tensor, recv: torch.Tensor):
+        assert send.is_contiguous() and recv.is_contiguous() and recv.numel() * recv.element_size() % (send.numel() * send.element_size()) == 0
+        N.check(self._lib.imdbn_allgather_bytes(comm, _ptr(send), _ptr(recv), send.numel() * send.element_size(), self._stream(send.device)),
+                "imdbn_allgather_bytes")
+        return recv
 
     def packed_floats(self, V, H) -> int:
         return int(self._lib.imdbn_packed_delta_floats(V, H))

@@ -90,6 +90,12 @@ SIGNATURES = {
                                C.POINTER(Rng), _P, _I64, _P, _SZ, _P]),
     "imdbn_rbm_clamped_step": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
                                       C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
+    "imdbn_rbm_assoc_update": (_INT, [C.POINTER(RbmDesc), _P, _I64, _P, _I64, _P, _I64, _P, _I64, _INT, C.POINTER(CdOpts), _P, _SZ, _P]),
+    "imdbn_comm_unique_id": (_INT, [_P]),
+    "imdbn_comm_init": (_INT, [C.POINTER(_P), _INT, _INT, _P]),
+    "imdbn_comm_destroy": (_INT, [_P]),
+    "imdbn_allreduce_sum_f32": (_INT, [_P, _P, _SZ, _P]),
+    "imdbn_allgather_bytes": (_INT, [_P, _P, _P, _SZ, _P]),
     "imdbn_rbm_clamped_stats": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
                                       C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
 }

@@ -710,3 +710,37 @@ def test_idbn_train_lookahead_with_a_ragged_last_batch_equals_plain_loop(tmp_pat
                 assert torch.equal(ta.data if hasattr(ta, "data") else ta, tb.data if hasattr(tb, "data") else tb), k
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.parametrize("V,H,B", [(300, 128, 33), (2048, 512, 64), (777, 45, 100)])
+def test_assoc_update_alone_matches_oracle(V, H, B, _native):
+    """imdbn_rbm_assoc_update (K3 on its own): the weight / bias update of rbm.py:209-224 from caller tensors."""
+    r, st, g = _mk(V, H, None, seed=V + 3 * H, sparsity=True, sparsity_factor=0.1)
+    vpos = (g.random((B, V), dtype=F32) > 0.7).astype(F32)
+    vneg = g.random((B, V), dtype=F32)                                    # real-valued: three-term planes
+    hpos, hneg = g.random((B, H), dtype=F32), g.random((B, H), dtype=F32)
+    lr, mom = r._lr_mom(7)
+    _native.assoc_update(r, P.T(vpos, DEV), P.T(hpos, DEV), P.T(vneg, DEV), P.T(hneg, DEV), lr, mom)
+    s = dict(pos_assoc=(vpos.T @ hpos).astype(F32), neg_assoc=(vneg.T @ hneg).astype(F32), pos_h_sum=hpos.sum(0, dtype=F32),
+             neg_h_sum=hneg.sum(0, dtype=F32), data_sum=vpos.sum(0, dtype=F32), v_sum=vneg.sum(0, dtype=F32))
+    O.apply_cd_update(st, s, lr, mom, B, True)
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r, k)), getattr(st, k), 2e-5, k, atol=2e-6)
+
+
+def test_rccl_through_the_c_abi_world_of_one(_native):
+    """imdbn_comm_* / imdbn_allreduce_sum_f32 / imdbn_allgather_bytes: a communicator of one rank over librccl (the multi-rank
+    flow is the caller's: carry the 128-byte id from rank 0 to the others, then the same calls)."""
+    uid = _native.comm_unique_id()
+    assert len(uid) == 128
+    comm = _native.comm_init(1, 0, uid)
+    try:
+        t = torch.arange(1000, device=DEV, dtype=torch.float32)
+        _native.comm_allreduce_sum(comm, t)
+        blk = torch.arange(4096, device=DEV, dtype=torch.uint8)
+        out = torch.zeros(4096, device=DEV, dtype=torch.uint8)
+        _native.comm_allgather(comm, blk, out)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32)) and torch.equal(out, blk)
+    finally:
+        _native.comm_destroy(comm)

@@ -16,6 +16,7 @@ _enabled = False
 _force = False
 _mode = "factors"
 _binary = False
+_rows_ok = set()      # per-rank row counts already agreed on by all ranks (validate_rows)
 
 
 def enable(group=None, force: bool = False, mode: str = "factors", binary_data: bool = False):
@@ -45,6 +46,28 @@ def enable(group=None, force: bool = False, mode: str = "factors", binary_data: 
 def disable():
     global _group, _enabled, _force, _mode, _binary
     _group, _enabled, _force, _mode, _binary = None, False, False, "factors", False
+    _rows_ok.clear()
+    from . import get_rng, PhiloxRng           # the shard offset of the draw source is data-parallel state: undo it
+    rng = get_rng()
+    if isinstance(rng, PhiloxRng):
+        rng.row0 = 0
+
+
+def validate_rows(B: int, device) -> None:
+    """Every rank must hold the SAME number of rows of a global batch: the Philox row offset is rank * B, the update is
+    normalised by B * world and the exchanges use equal block sizes.  The first time a row count is seen, the ranks agree on it
+    with one small all-reduce (all ranks meet a new count at the same step of a lock-step loader); a mismatch -- e.g. a ragged
+    last batch split unevenly -- raises on every rank instead of hanging in the exchange or silently mis-normalising."""
+    if B in _rows_ok or world_size() == 1:
+        return
+    import torch.distributed as dist
+    t = torch.tensor([float(B), -float(B)], device=device if dist.get_backend(_group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_group)
+    hi, lo = int(t[0].item()), int(-t[1].item())
+    if hi != lo:
+        raise RuntimeError(f"imdbn data parallelism: ranks hold between {lo} and {hi} rows of this global batch; every rank must hold the "
+                           f"same number (drop the ragged last batch or pad it: imdbn.datasets.DeviceLoader(drop_last=True))")
+    _rows_ok.add(B)
 
 
 def binary_data() -> bool:

@@ -195,6 +195,7 @@ class RBM(nn.Module):
         dp = _E.dp
         if dp.active():
             B = x.size(0)
+            dp.validate_rows(B, x.device)
             if dp.mode() == "factors" and hasattr(eng, "factor_mode_ok") and eng.factor_mode_ok(self, B):
                 # exchange the factors (~7 MB per rank at 10000 x 1500) instead of the fp32 statistics (60 MB)
                 block = eng.cd_factors(self, x, CD, rng, **kw)
@@ -330,6 +331,7 @@ class RBM(nn.Module):
         if dp.active():
             # this rank's rows of the global batch; one all-reduce of the packed statistics
             B = vk.size(0)
+            dp.validate_rows(B, vk.device)
             buf = eng.packed_buffer(self) if hasattr(eng, "packed_buffer") else None
             packed = eng.clamped_stats(self, vk, km, init, mu, CD, sample_h, sample_v, reclamp_negative, rng, out=buf)
             dp.all_reduce_sum(packed)

@@ -189,3 +189,46 @@ def test_two_rank_train_joint_equals_single_rank(tmp_path, monkeypatch):
         assert rel_fro(a[k], ref[k]) < tol, k
     assert np.allclose(a["top1"], ref["top1"]) and np.allclose(a["ce"], ref["ce"], rtol=1e-4) and np.allclose(a["mse"], ref["mse"], rtol=1e-4)
     assert np.allclose(a["cd"], ref["cd"], rtol=1e-4)
+
+
+def _ragged_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from imdbn import engine as E
+    from oracle_engine import OracleEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E.set_engine_for_testing(OracleEngine())
+    E.dp.enable(mode="allreduce")
+    r, X = _make(groups=False)
+    E.set_rng(E.PhiloxRng(SEED))
+    rows = 8 if rank == 0 else 5                          # an unevenly split ragged batch
+    msg = ""
+    try:
+        r.train_epoch(torch.from_numpy(X[0, :rows]), 0, 10, CD=1)
+    except RuntimeError as e:
+        msg = str(e)
+    E.dp.disable()
+    row0_after = E.get_rng().row0
+    with open(os.path.join(out_dir, f"ragged{rank}.txt"), "w") as f:
+        f.write(f"{row0_after}|{msg}")
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_raise_on_every_rank_instead_of_hanging(tmp_path):
+    """ranks with different row counts would pick different block sizes / Philox rows and mis-normalise; the first
+    time a row count is seen the ranks agree on it, and a mismatch raises on all of them.  disable() restores the row offset."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, PKG, HERE, os.environ.get("PYTHONPATH", "")])
+    mp.spawn(_ragged_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        row0, msg = open(tmp_path / f"ragged{rank}.txt").read().split("|", 1)
+        assert "between 5 and 8 rows" in msg, msg
+        assert int(row0) == 0

@@ -744,3 +744,25 @@ def test_rccl_through_the_c_abi_world_of_one(_native):
         assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32)) and torch.equal(out, blk)
     finally:
         _native.comm_destroy(comm)
+
+
+def test_bench_multi_gpu_form_starts_its_own_ranks():
+    """`python bench.py --gpus 2` typed as is (no torchrun): the parent starts the ranks as child processes before touching the
+    GPU and relays rank 0's JSON line.  Rehearsed with two ranks sharing this one GPU over gloo (RCCL needs one GPU per rank);
+    both exchanges are timed in the run and the replicas must stay bit-identical."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["replicas_identical"] is True and d["config"]["dp_exchange"].startswith("factors")
+    o = d["dp_other_exchange"]
+    assert o["dp_exchange"].startswith("allreduce") and o["replicas_identical"] is True and o["value"] > 0

@@ -90,7 +90,9 @@ __device__ __forceinline__ void store_tr_pc(const OperandOut& o, const uint32_t 
 // LDS staging of a block's K16-blocked operand tile: buf[t][kb][row][16] for the block's `nkb` 16-column groups
 // x `rows` batch rows.  2-byte scattered global stores are processed about a lane at a time (24 of them per
 // thread were ~5 us of the fused K2 epilogue); through LDS the tile leaves as coalesced 16-B stores.
-struct RmStage { bf16_t* buf; int nkb, rows; int col0, row0; };
+// Passed BY VALUE (buf == nullptr: no stage): as `const RmStage*` selected with `staged ? &stg : nullptr` the struct lived in
+// scratch memory (32 B per lane on every kernel with the general epilogue, reloaded inside the per-element code).
+struct RmStage { bf16_t* buf = nullptr; int nkb = 0, rows = 0; int col0 = 0, row0 = 0; };
 
 template <int R>
 __device__ __forceinline__ void stage_rm_pc(const OperandOut& o, const RmStage& g, const uint32_t (&pc)[3][R], int b0, int col) {
@@ -120,16 +122,16 @@ __device__ __forceinline__ void flush_rm_stage(const OperandOut& o, const RmStag
 // form goes to the block's LDS stage (the caller flushes it), otherwise straight to memory
 template <int R>
 __device__ __forceinline__ void store_forms(const OperandOut& o, const float (&x)[R], bool rm, bool tr, int b0, int col, int N, int Bp,
-                                            const RmStage* stg = nullptr) {
+                                            const RmStage stg = RmStage{}) {
     uint32_t pc[3][R];
     rm = rm && o.rm && col < o.ldrm;
     if (rm && tr && o.rm_terms == o.tr_terms) {
         pieces<R>(x, o.rm_terms, pc);
-        if (stg) stage_rm_pc<R>(o, *stg, pc, b0, col); else store_rm_pc<R>(o, pc, b0, col);
+        if (stg.buf) stage_rm_pc<R>(o, stg, pc, b0, col); else store_rm_pc<R>(o, pc, b0, col);
         store_tr_pc<R>(o, pc, b0, col, N, Bp);
         return;
     }
-    if (rm) { pieces<R>(x, o.rm_terms, pc); if (stg) stage_rm_pc<R>(o, *stg, pc, b0, col); else store_rm_pc<R>(o, pc, b0, col); }
+    if (rm) { pieces<R>(x, o.rm_terms, pc); if (stg.buf) stage_rm_pc<R>(o, stg, pc, b0, col); else store_rm_pc<R>(o, pc, b0, col); }
     if (tr) { pieces<R>(x, o.tr_terms, pc); store_tr_pc<R>(o, pc, b0, col, N, Bp); }
 }
 
@@ -205,7 +207,7 @@ __device__ __forceinline__ void load_side(const FinishArgs& a, int col, int b0, 
 // epilogue).  Sampling (vmode) stays a run-time switch in both.
 template <int R, bool EX>
 __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, int b0, const float (&xs)[R], const SideIn<R>& sd, float& csum,
-                                                  const RmStage* stg, int bshape, int bcols) {
+                                                  const RmStage stg, int bshape, int bcols) {
     const bool cok = col < a.N;
     const bool grp = EX && cok && in_group(a, col);
     const int cc = min(col, a.N - 1);
@@ -288,7 +290,7 @@ __device__ __forceinline__ float finish_rows_impl(const FinishArgs& a, int col, 
 
 template <int R>
 __device__ __forceinline__ float finish_rows(const FinishArgs& a, int col, int b0, const float (&xs)[R], const SideIn<R>& sd, float& csum,
-                                             const RmStage* stg = nullptr, int bshape = -1, int bcols = 0) {
+                                             const RmStage stg = RmStage{}, int bshape = -1, int bcols = 0) {
     if (a.simple) return finish_rows_impl<R, false>(a, col, b0, xs, sd, csum, stg, bshape, bcols);
     return finish_rows_impl<R, true>(a, col, b0, xs, sd, csum, stg, bshape, bcols);
 }
@@ -302,7 +304,7 @@ __device__ __forceinline__ float finish_rows(const FinishArgs& a, int col, int b
 
 // one column x 8 rows per thread: part_row = index of this 8-row group in the column-sum partials
 __device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int b0, const float (&xs)[8], int part_row, const SideIn<8>& sd,
-                                              const RmStage* stg = nullptr, int bshape = -1, int bcols = 0) {
+                                              const RmStage stg = RmStage{}, int bshape = -1, int bcols = 0) {
     float csum;
     const float lsum = finish_rows<8>(a, col, b0, xs, sd, csum, stg, bshape, bcols);
     if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void finish(const FinishArgs a) {
     load_side<2>(a, col, b0 + 2 * kq, sd);
     const bool staged = a.rm_src && !a.logits_only;
     const RmStage stg{rmst, 4, 8, (int)blockIdx.x * 64, b0};
-    const float lsum = finish_rows<2>(a, col, b0 + 2 * kq, x2, sd, csum, staged ? &stg : nullptr);
+    const float lsum = finish_rows<2>(a, col, b0 + 2 * kq, x2, sd, csum, staged ? stg : RmStage{});
     stamp(st, sblk, 3);
     __syncthreads();                                   // part[] is consumed: reuse it for the column / loss sums
     if (staged) flush_rm_stage(a.op, stg);
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
     if (c == 0) fl[kq] = (any ? FLAG_INEXACT : 0) | (anyb ? FLAG_NONBINARY : 0);
     cs[kq][c] = csum;
     const RmStage stg{rmst, 4, 8, (int)blockIdx.x * 64, g0};
-    store_forms<2>(a.op, x, true, true, b0, col, a.N, a.Bp, &stg);
+    store_forms<2>(a.op, x, true, true, b0, col, a.N, a.Bp, stg);
     __syncthreads();
     flush_rm_stage(a.op, stg);
     if (kq == 0) {
@@ -674,7 +676,7 @@ __device__ __forceinline__ void prep_item_process(const PrepArgs& a, int tx, int
         // the order of prep_operand: four row pairs, combined left to right
         const float csum = (((0.f + x[0] + x[1]) + (0.f + x[2] + x[3])) + (0.f + x[4] + x[5])) + (0.f + x[6] + x[7]);
         const bool any = __any(inexact ? 1 : 0) != 0, anyb = __any(nonbin ? 1 : 0) != 0;      // the wave = this group's 64 columns
-        store_forms<8>(a.op, x, true, true, b0, col, a.N, a.Bp, &stg);
+        store_forms<8>(a.op, x, true, true, b0, col, a.N, a.Bp, stg);
         if (a.flag && c == 0) a.flag[by * ntx + tx] = (any ? FLAG_INEXACT : 0) | (anyb ? FLAG_NONBINARY : 0);
         if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)by * a.N + col] = csum;
     }

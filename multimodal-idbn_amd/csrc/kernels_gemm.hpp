@@ -454,7 +454,7 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     // the reduction buffer is free again: it stages the K16-blocked operand tile [term][2 column groups][64 rows][16]
     const bool staged = fa.rm_src && !fa.logits_only && TR == 32;      // needs 16-column-aligned tiles
     const RmStage stg{reinterpret_cast<bf16_t*>(red), 2, 64, n0, mb};
-    lsum = finish_rows8(fa, ecol, mb + oct * 8, xs, (mb >> 3) + oct, side, staged ? &stg : nullptr);
+    lsum = finish_rows8(fa, ecol, mb + oct * 8, xs, (mb >> 3) + oct, side, staged ? stg : RmStage{});
     stamp(st, sblk, 5);
     if (staged) {
         __syncthreads();

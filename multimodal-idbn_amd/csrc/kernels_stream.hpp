@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     stamp(st, sblk, 5);
     // ---- epilogue of `finish`, fused: bias, sigmoid, Bernoulli sample, operand forms, column sums
     if (fa.lean) (void)finish_lean8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, sl8, 1, 32);
-    else         (void)finish_rows8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, side, nullptr);
+    else         (void)finish_rows8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, side);
     stamp(st, sblk, 6);
 }
 
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * K2S_W, 2) void k2_stream(const K2sArgs a, cons
         }
         const int bshape = isA ? 1 : 2, bcols = isA ? min(TR, 32) : TR - 32;
         if (fa.lean) lsum = finish_lean8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, sl, bshape, bcols);
-        else         lsum = finish_rows8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, side, nullptr, bshape, bcols);
+        else         lsum = finish_rows8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, side, RmStage{}, bshape, bcols);
     }
     stamp(st, sblk, 4);
     if (fa.loss_part) {

@@ -5,20 +5,7 @@ set -o pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil MfmaFlopsBF16; do
-  (cd /tmp && timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1)
+  (cd /tmp && timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1)
   echo "== $c exit $?"; find gpurun_out/pmc_$c -name "*.csv" | head -5
 done
-python3 - <<'PY'
-import csv, glob, collections
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    fs = glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)
-    if not fs: print(c, "no csv"); continue
-    acc = collections.defaultdict(list)
-    rows = list(csv.DictReader(open(fs[0])))
-    if rows: print(c, "columns:", list(rows[0].keys()))
-    for r in rows:
-        if r.get("Counter_Name") == c:
-            acc[r["Kernel_Name"][:48]].append(float(r["Counter_Value"]))
-    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:8]:
-        print(f"  {c:10s} {k:48s} n={len(v):4d} mean={sum(v)/len(v):14.1f}")
-PY
+python3 tools/pmc_summarize.py

@@ -144,10 +144,14 @@ def other_configs(dev):
             xb = [b[0].to(dev) for b in dl]
 
             def c2():      # the interleaved layer loop of iDBN.train (idbn.py:195-204) with its next-batch lookahead
+                last = len(d.layers) - 1
                 for i, v in enumerate(xb):
                     for li, r in enumerate(d.layers):
-                        r.train_epoch(v, 0, 1, CD=1, next_data=xb[(i + 1) % len(xb)] if li == 0 else None)
-                        v = r.forward(v)
+                        nd = xb[(i + 1) % len(xb)] if li == 0 else None
+                        if li < last:
+                            _, v = r.train_epoch(v, 0, 1, CD=1, next_data=nd, return_forward=True)
+                        else:
+                            r.train_epoch(v, 0, 1, CD=1, next_data=nd)
             t = timeit(c2, 4, 1) / len(xb)
             out["C2_stack"] = {"ms_per_batch": 1e3 * t, "batches_per_s": 1.0 / t, "bound": "layer 1 HBM (see roofline); layer 2 + forwards launch/latency",
                                "ref_cpu_ms_per_batch": 213.0}

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IMDBN_ABI_VERSION 2
+#define IMDBN_ABI_VERSION 3
 
 /* error codes (negative) */
 #define IMDBN_E_INVALID   (-1)   /* bad argument (shape, null pointer, alignment) */
@@ -126,6 +126,12 @@ typedef struct imdbn_cd_opts {
      * exactness map, column sums, one bf16 plane) instead of all three-term operand forms.  Honoured only when the positive
      * phase can read bit planes (16-B aligned weight rows, V > 1024); the later cd_step on that batch must pass data_binary = 1. */
     int32_t next_binary;
+    /* -- forward pass fused behind the update (imdbn_rbm_cd_step only; NULL = off): after the weights are updated, the
+     * hidden probabilities sigmoid(data @ W + hid_bias) of the SAME batch under the NEW weights are written to
+     * fwd_out[B][H] (row stride ld_fwd floats) -- the `train_epoch(v); v = forward(v)` pair of the layer loop
+     * (idbn.py:195-204) as one call: the batch's operand forms are still in the workspace, so nothing is prepared twice. */
+    float*  fwd_out;
+    int64_t ld_fwd;
 } imdbn_cd_opts;
 
 /* ---- plumbing ------------------------------------------------------------------------- */
@@ -154,6 +160,12 @@ int    imdbn_debug_ws_offset(int V, int H, int B, const char* name, size_t* offs
 int imdbn_rbm_prop_up(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B, float T,
                       imdbn_rng* rng, float* out_prob, int64_t ldo, float* out_sample, int64_t lds,
                       void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+/* forward(v) at T = 1: out_prob[B][H] = sigmoid(v W + c).  data_binary = 1: the caller asserts v is 0/1 (checked on the
+ * device, NaN on a false promise): the batch is then read as a bit plane by the streaming K1.  Bit-identical to the fused
+ * forward of imdbn_rbm_cd_step (imdbn_cd_opts.fwd_out) for the same batch, weights and data_binary. */
+int imdbn_rbm_forward(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B, int data_binary,
+                      float* out_prob, int64_t ldo, void* ws, size_t ws_bytes, imdbn_stream_t stream);
 
 /* ---- free energy   F(v) = -v.b - sum_j softplus(c_j + (vW)_j)   (imdbn/utils/energy_utils.py:19-28; the
  *      `joint_rbm.free_energy` that imdbn.py:455-474 probes for and the reference never defines) -------- */

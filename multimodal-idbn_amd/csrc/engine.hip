@@ -368,7 +368,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
     f.simple = (f.T == 1.0f && !(f.sigma > 0.f) && !f.mu && !f.clamp && f.n_groups == 0 && !f.logits_only) ? 1 : 0;
     // lean epilogue of the streaming kernels (kernels_ew.hpp finish_lean8): decided once all outputs are known (below)
     auto lean_ok = [&](const FinishArgs& g) {
-        return g.simple && (g.vmode == 0 || g.vmode == 1) && !g.out_prob && !g.out_final && !(g.rm_src && g.op.rm) &&
+        return g.simple && (g.vmode == 0 || g.vmode == 1) && !g.out_final && !(g.rm_src && g.op.rm) &&
                (g.vmode == 0 || g.uni.tape || (g.uni.row0 & 3) == 0) ? 1 : 0;
     };
     const int mb = L.Bp / 64;
@@ -545,7 +545,7 @@ int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_
     p.op.bits = bits; p.op.bits_shape = 0;
     p.zero = c.L.k1s_cnt; p.n_zero = (c.L.Bp / 64) * c.L.k1s_tiles;      // first launch of a call: arrival counters of k1_stream
     p.in = in; p.ld = ld; p.B = c.L.B; p.Bp = c.L.Bp; p.N = N;
-    p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = terms; p.op.Bp = c.L.Bp;
+    p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = rm ? terms : 0; p.op.Bp = c.L.Bp;
     p.op.tr = tr; p.op.tr_ts = (int64_t)N * c.L.Bp; p.op.tr_terms = terms;
     p.flag = flag;
     p.colsum_part = colsum;
@@ -955,6 +955,22 @@ int imdbn_rbm_prop_up(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int 
     return c.rng.finish();
 }
 
+// forward(v) at T = 1 on exactly the path the fused forward of imdbn_rbm_cd_step takes for the same batch (bit-identical):
+// a 0/1 batch is read as a bit plane by k1_stream, anything else through the three-term operand form
+int imdbn_rbm_forward(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B, int data_binary, float* out_prob, int64_t ldo,
+                      void* ws, size_t ws_bytes, imdbn_stream_t stream) {
+    CHK(check_desc(d, false));
+    if (!v || !out_prob || ldv < d->V || ldo < d->H) return fail(IMDBN_E_INVALID, "forward: bad tensor argument");
+    Ctx c(d, nullptr, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    const bool bits = data_binary && vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024;       // prop() then launches k1_stream
+    CHK(prep(c, v, ldv, d->V, bits ? nullptr : c.L.vis_rm[0], c.L.Vpad, nullptr, c.L.flags, nullptr, 3, bits ? c.L.vis_bits[0] : nullptr));
+    FinishArgs f = new_finish();
+    f.out_prob = out_prob; f.ld_prob = ldo;
+    CHK(prop(c, true, OpIn{c.L.vis_rm[0], c.nw == 1 ? 1 : 0, c.L.flags, bits ? c.L.vis_bits[0] : nullptr, bits ? 2 : 0}, f));
+    return 0;
+}
+
 int imdbn_rbm_free_energy(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B, float* out_F, void* ws, size_t ws_bytes,
                           imdbn_stream_t stream) {
     CHK(check_desc(d, false));
@@ -1070,6 +1086,15 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
     CHK(c.rng.finish());
     const BiasArgs bias = make_bias(c, o, o->sparsity != 0, (float)B, loss_out);
     CHK(launch_assoc(c, 0, o, c.nw == 1 ? 1 : 0, c.L.flags, 1, (float)B, nullptr, &bias));
+    if (o->fwd_out) {
+        // forward(data) under the updated weights (idbn.py:195-204: train_epoch(v); v = forward(v)): the positive-phase
+        // propagation once more -- same operand forms, still in the workspace -- with the probabilities as the only output
+        if (o->ld_fwd < d->H) return fail(IMDBN_E_INVALID, "cd_step: ld_fwd %lld < H %d", (long long)o->ld_fwd, d->H);
+        FinishArgs f = new_finish();
+        f.out_prob = o->fwd_out; f.ld_prob = o->ld_fwd;
+        const bool bits = o->data_binary && vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024;      // as imdbn_rbm_forward
+        CHK(prop(c, true, OpIn{c.L.vis_rm[0], c.nw == 1 ? 1 : 0, c.L.flags, bits ? c.L.vis_bits[0] : nullptr, bits ? 2 : 0}, f));
+    }
     return 0;
 }
 

@@ -320,7 +320,7 @@ __device__ __forceinline__ float finish_rows8(const FinishArgs& a, int col, int 
 // ---- lean epilogue of the CD propagations: one column x 8 consecutive batch rows (b0 % 8 == 0) --------------------------
 // Exactly the arithmetic (and summation order) of finish_rows_impl<8, false> for the configurations the CD step uses:
 // T = 1, no noise / mu-pull / clamp / softmax groups, outputs = transposed operand plane(s), bit plane of the sample,
-// column-sum partial, squared-error partial.  Side inputs: the bias and (with a loss reference) 8 reference values.
+// column-sum partial, squared-error partial, fp32 probabilities (the fused forward of cd_step).  Side inputs: the bias and (with a loss reference) 8 reference values.
 struct SideLean { float bias; float ref[8]; };
 
 __device__ __forceinline__ void load_side_lean(const FinishArgs& a, int col, int b0, SideLean& s) {
@@ -371,6 +371,11 @@ __device__ __forceinline__ float finish_lean8(const FinishArgs& a, int col, int 
     if (a.op.bits) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) store_bits_row(a.op, xf[i] != 0.f, col, b0 + i, b0 + i < a.Bp, bshape, bcols);
+    }
+    if (a.out_prob && cok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (b0 + i < a.B) a.out_prob[(int64_t)(b0 + i) * a.ld_prob + col] = xp[i];
     }
     if (a.colsum_part && cok) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
     return lsum;

@@ -34,6 +34,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class HipEngine:
     name = "hip"
+    fused_forward = True        # cd_step(forward=True): imdbn_cd_opts.fwd_out
 
     def __init__(self):
         self._lib = N.lib()
@@ -194,6 +195,18 @@ class HipEngine:
             return out, smp
         return out
 
+    def forward(self, rbm, v, data_binary=None):
+        """forward(v) at T = 1 (imdbn_rbm_forward): a 0/1 batch goes through the streaming K1 as a bit plane."""
+        d = self._desc(rbm, False)
+        x = _f32c(v, "v")
+        B, dev = x.size(0), x.device
+        out = torch.empty(B, d.H, device=dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        binary = int(self.data_is_binary(v) if data_binary is None else bool(data_binary))
+        N.check(self._lib.imdbn_rbm_forward(C.byref(d), _ptr(x), x.stride(0), B, binary, _ptr(out), out.stride(0), _ptr(ws), ws.numel(),
+                                             self._stream(dev)), "imdbn_rbm_forward")
+        return out
+
     def free_energy(self, rbm, v):
         d = self._desc(rbm, False)
         v = _f32c(v, "v")
@@ -291,10 +304,11 @@ class HipEngine:
             ok = self._pf_ok[key] = bool(self._lib.imdbn_rbm_prefetch_ok(C.byref(d), B))
         return ok
 
-    def cd_step(self, rbm, data, lr, mom, cd_k, rng, next_data=None, data_binary=None):
+    def cd_step(self, rbm, data, lr, mom, cd_k, rng, next_data=None, data_binary=None, forward=False):
         """One CD-k update.  ``next_data``: the batch the NEXT cd_step of this shape will get -- its operand forms are
         then prepared by extra blocks of this call's first negative-phase launch and the
-        next call skips its own preparation when it is handed that very tensor, unmodified."""
+        next call skips its own preparation when it is handed that very tensor, unmodified.
+        ``forward``: also return ``forward(data)`` under the updated weights (one more propagation in the same call)."""
         d = self._desc(rbm, True)
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
@@ -314,11 +328,17 @@ class HipEngine:
             nxt = next_data
             o.next_data, o.ld_next, o.next_slot = nxt.data_ptr(), nxt.stride(0), (2 if o.data_slot == 1 else 1)
             o.next_binary = int(self.data_is_binary(next_data))
+        fwd = None
+        if forward:
+            fwd = torch.empty(B, d.H, device=dev)
+            o.fwd_out, o.ld_fwd = fwd.data_ptr(), fwd.stride(0)
         N.check(self._lib.imdbn_rbm_cd_step(C.byref(d), _ptr(x), x.stride(0), B, C.byref(o), C.byref(r), _ptr(loss),
                                              _ptr(ws), ws.numel(), self._stream(dev)), "imdbn_rbm_cd_step")
         self._done(rng, r, sched)
         if nxt is not None:                      # the strong reference keeps the address from being recycled
             self._pf[key] = (self._ident(nxt), int(o.next_slot), nxt)
+        if forward:
+            return loss.reshape(()), fwd
         return loss.reshape(())
 
     def assoc_update(self, rbm, vpos, hpos, vneg, hneg, lr, mom):

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 MAX_GROUPS = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 PARITY_F32, FAST_BF16 = 0, 1
 RNG_PHILOX, RNG_REPLAY = 0, 1
 
@@ -48,7 +48,8 @@ class CdOpts(C.Structure):
                 ("sparsity", C.c_int32), ("sparsity_target", C.c_float),
                 ("sample_h", C.c_int32), ("sample_v", C.c_int32), ("reclamp_negative", C.c_int32),
                 ("next_data", C.c_void_p), ("ld_next", C.c_int64), ("next_slot", C.c_int32), ("data_slot", C.c_int32),
-                ("data_binary", C.c_int32), ("next_binary", C.c_int32)]
+                ("data_binary", C.c_int32), ("next_binary", C.c_int32),
+                ("fwd_out", C.c_void_p), ("ld_fwd", C.c_int64)]
 
 
 _P = C.c_void_p
@@ -70,6 +71,7 @@ SIGNATURES = {
     "imdbn_debug_stamps": (_INT, [C.POINTER(C.c_longlong), _INT]),
     "imdbn_debug_ws_offset": (_INT, [_INT, _INT, _INT, C.c_char_p, C.POINTER(_SZ)]),
     "imdbn_rbm_prop_up": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _F, C.POINTER(Rng), _P, _I64, _P, _I64, _P, _SZ, _P]),
+    "imdbn_rbm_forward": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _INT, _P, _I64, _P, _SZ, _P]),
     "imdbn_rbm_free_energy": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _P, _P, _SZ, _P]),
     "imdbn_rbm_prop_down": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _F, _INT, _P, _I64, _P, _SZ, _P]),
     "imdbn_rbm_sample_visible": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(Rng), _P, _I64, _P]),

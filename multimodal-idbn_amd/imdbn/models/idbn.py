@@ -111,9 +111,14 @@ class iDBN:
             while cur is not None:
                 nxt = dev_batch(next(it, None))
                 v = cur
+                last = len(self.layers) - 1
                 for li, rbm in enumerate(self.layers):
-                    loss = rbm.train_epoch(v, epoch, epochs, CD=self.cd_k, next_data=nxt if li == 0 else None)
-                    v = rbm.forward(v)
+                    # update + forward of the same batch as one engine call; the top layer's forward (computed and
+                    # dropped by the reference, idbn.py:203) has no side effect and is not run
+                    if li < last:
+                        loss, v = rbm.train_epoch(v, epoch, epochs, CD=self.cd_k, next_data=nxt if li == 0 else None, return_forward=True)
+                    else:
+                        loss = rbm.train_epoch(v, epoch, epochs, CD=self.cd_k, next_data=nxt if li == 0 else None)
                     losses.append(loss)
                 cur = nxt
             if losses:

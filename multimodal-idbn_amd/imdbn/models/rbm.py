@@ -117,7 +117,12 @@ class RBM(nn.Module):
     @torch.no_grad()
     def forward(self, v: torch.Tensor, T: float = 1.0) -> torch.Tensor:
         """p(h|v) = sigmoid((v W + c)/max(1e-6,T))   (rbm.py:92)."""
-        out = self._eng().prop_up(self, self._in(v), T=T)
+        eng = self._eng()
+        if T == 1.0 and hasattr(eng, "forward") and hasattr(eng, "data_is_binary"):
+            # the same path as the forward fused into train_epoch(return_forward=True): bit-identical results
+            out = eng.forward(self, self._in(v), data_binary=eng.data_is_binary(v))
+        else:
+            out = eng.prop_up(self, self._in(v), T=T)
         out._imdbn_binary = False      # probabilities: the next layer's update need not ask (HipEngine.data_is_binary)
         return out
 
@@ -173,13 +178,17 @@ class RBM(nn.Module):
     # ---- CD-k update (rbm.py:180-227) -----------------------------------------------------------
     @torch.no_grad()
     def train_epoch(self, data: torch.Tensor, epoch: int, max_epochs: int, CD: int = 1,
-                    next_data: Optional[torch.Tensor] = None):
+                    next_data: Optional[torch.Tensor] = None, return_forward: bool = False):
         """One CD-k update on one mini-batch (the name is the reference's); returns the 0-d MSE loss.
 
         ``next_data`` (extension, optional): the batch the following ``train_epoch`` call will receive.  Its operand
         forms are prepared by extra blocks of one of this call's launches; hand that same tensor, unmodified, to the next
         call and it skips its own preparation (results are bit-identical either way; a modified, different or
         ineligible tensor is simply prepared again).
+
+        ``return_forward`` (extension): return ``(loss, self.forward(data))`` -- the pair of calls of the layer loop
+        (idbn.py:195-204) -- with the forward pass run inside the same engine call where it can be (the batch's operand
+        forms are still in the workspace); bit-identical to the two separate calls.
 
         With data parallelism enabled (``imdbn.engine.dp.enable()``) ``data`` is this rank's shard
         of the global batch: the ranks exchange their factor blocks (or all-reduce the statistics, see
@@ -196,6 +205,7 @@ class RBM(nn.Module):
         if dp.active():
             B = x.size(0)
             dp.validate_rows(B, x.device)
+            ret = (lambda loss: (loss, self.forward(data))) if return_forward else (lambda loss: loss)
             if dp.mode() == "factors" and hasattr(eng, "factor_mode_ok") and eng.factor_mode_ok(self, B):
                 # exchange the factors (~7 MB per rank at 10000 x 1500) instead of the fp32 statistics (60 MB)
                 block = eng.cd_factors(self, x, CD, rng, **kw)
@@ -206,15 +216,22 @@ class RBM(nn.Module):
                     wires = dp.all_gather_blocks(eng.compact_gather_buffer(self, B, dp.world_size(), binary), wire)
                     if hasattr(eng, "apply_factors_wire"):       # the head of the blocks is read from the wire blocks in place
                         planes = eng.unpack_factors(self, wires, B, binary, planes_only=True)
-                        return eng.apply_factors_wire(self, wires, planes, B, B * dp.world_size(), lr, mom)
+                        return ret(eng.apply_factors_wire(self, wires, planes, B, B * dp.world_size(), lr, mom))
                     gathered = eng.unpack_factors(self, wires, B, binary)
                 else:
                     gathered = dp.all_gather_blocks(eng.gather_buffer(self, B, dp.world_size()), block)
-                return eng.apply_factors(self, gathered, B, B * dp.world_size(), lr, mom)
+                return ret(eng.apply_factors(self, gathered, B, B * dp.world_size(), lr, mom))
             buf = eng.packed_buffer(self) if hasattr(eng, "packed_buffer") else None
             packed = eng.cd_stats(self, x, CD, rng, out=buf, **kw)
             dp.all_reduce_sum(packed)
-            return eng.apply_delta(self, packed, B * dp.world_size(), lr, mom)
+            return ret(eng.apply_delta(self, packed, B * dp.world_size(), lr, mom))
+        if return_forward:
+            if not getattr(eng, "fused_forward", False):
+                loss = eng.cd_step(self, x, lr, mom, CD, rng, **({"next_data": next_data} if next_data is not None else {}), **kw)
+                return loss, self.forward(data)
+            loss, h = eng.cd_step(self, x, lr, mom, CD, rng, next_data=next_data, forward=True, **kw)
+            h._imdbn_binary = False
+            return loss, h
         if next_data is not None:
             return eng.cd_step(self, x, lr, mom, CD, rng, next_data=next_data, **kw)
         return eng.cd_step(self, x, lr, mom, CD, rng, **kw)

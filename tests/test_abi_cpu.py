@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_sizes():
     lib = native.lib()
-    assert lib.imdbn_version() == native.ABI_VERSION == 2      # include/imdbn_engine.h IMDBN_ABI_VERSION
+    assert lib.imdbn_version() == native.ABI_VERSION == 3      # include/imdbn_engine.h IMDBN_ABI_VERSION
     assert lib.imdbn_ws_bytes(10000, 1500, 64) > 0
     assert lib.imdbn_ws_bytes(10000, 1500, 64) <= 128 << 20        # scratch stays small next to 288 GB
     assert lib.imdbn_ws_bytes(0, 10, 1) == 0
@@ -38,7 +38,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(native.RbmDesc) == 8 * 7 + 4 * 4 + 4 * 8
     assert C.sizeof(native.Rng) == 8 + 8 * 3 + 8 * 4 + 8 * 3
     assert C.sizeof(native.ChainStep) == 24
-    assert C.sizeof(native.CdOpts) == 72            # 9 x 4 B + pad + next_data, ld_next, next_slot, data_slot, data_binary, next_binary
+    assert C.sizeof(native.CdOpts) == 88            # 9 x 4 B + pad + next_data, ld_next, next_slot, data_slot, data_binary, next_binary, fwd_out, ld_fwd
 
 
 def test_no_gpu_call_reports_nodevice_as_exception():

@@ -589,6 +589,40 @@ def test_next_batch_prefetch_is_bit_identical_and_guards_against_stale_data(V, H
             assert len(_native._pf) == 0
 
 
+@pytest.mark.parametrize("V,H,B,binary", [(10000, 1500, 64, True), (1500, 500, 64, False), (2048, 512, 40, True),
+                                          (777, 45, 100, True), (4099, 130, 33, False), (4096, 258, 70, True)])
+def test_update_with_fused_forward_equals_the_two_calls(V, H, B, binary, _native):
+    """train_epoch(return_forward=True) (imdbn_cd_opts.fwd_out: the layer loop's `train_epoch(v); v = forward(v)` as one
+    engine call) against the two separate calls: same weights, same loss, same probabilities, bit for bit -- with and
+    without the next-batch hint, for 0/1 batches (bit-plane path) and real-valued ones; forward() against the oracle."""
+    from imdbn import engine as E
+    g = np.random.default_rng(V + B)
+    mk = (lambda: (g.random((B, V), dtype=F32) > 0.8).astype(F32)) if binary else (lambda: g.random((B, V), dtype=F32))
+    Xs = [P.T(mk(), DEV) for _ in range(3)]
+    r1, st, _ = _mk(V, H, None, seed=5)
+    r2, _, _ = _mk(V, H, None, seed=5)
+    with E.use_rng(E.PhiloxRng(seed=8)):
+        a = []
+        for x in Xs:
+            l = r1.train_epoch(x, 0, 1, CD=1)
+            a.append((float(l), r1.forward(x)))
+    with E.use_rng(E.PhiloxRng(seed=8)):
+        b = []
+        for i, x in enumerate(Xs):
+            l, h = r2.train_epoch(x, 0, 1, CD=1, next_data=Xs[i + 1] if i + 1 < len(Xs) and i != 1 else None, return_forward=True)
+            b.append((float(l), h))
+    for (la, ha), (lb, hb) in zip(a, b):
+        assert la == lb and torch.equal(ha, hb)
+        assert getattr(hb, "_imdbn_binary", None) is False
+    for k in P.KEYS:
+        ta, tb = getattr(r1, k), getattr(r2, k)
+        assert torch.equal(ta.data if hasattr(ta, "data") else ta, tb.data if hasattr(tb, "data") else tb), k
+    # forward() itself against the oracle's sigmoid(v W + c) with the engine's final weights
+    W, c = P.N(r2.W), P.N(r2.hid_bias)
+    want = 1.0 / (1.0 + np.exp(-(P.N(Xs[-1]).astype(np.float64) @ W.astype(np.float64) + c.astype(np.float64))))
+    assert_close(P.N(b[-1][1]), want.astype(F32), 1e-5, "forward", atol=1e-6)
+
+
 @pytest.mark.parametrize("binary", [False, True])
 def test_factor_wire_form_round_trips_and_poisons_on_a_false_promise(binary, _native):
     """Wire form of the factor block (bit-packed visible planes): pack -> (all-gather) -> unpack gives apply_factors

@@ -231,6 +231,15 @@ int    imdbn_factor_compact_bytes(int V, int H, int B, int binary_data, size_t* 
 int    imdbn_rbm_pack_factors(int V, int H, int B, int binary_data, const void* block, void* compact, imdbn_stream_t stream);
 int    imdbn_rbm_unpack_factors(int V, int H, int B, int binary_data, const void* compact, size_t compact_stride, int n_ranks,
                                 void* gathered, size_t full_stride, int planes_only, imdbn_stream_t stream);
+/* The two halves of a data-parallel step as ONE call each (a binder's step is: cd_factors_wire, all-gather of the wire blocks,
+ * apply_wire).  cd_factors_wire = cd_factors + pack_factors, and it honours the next-batch prefetch fields of imdbn_cd_opts
+ * (next_data / next_slot / data_slot / next_binary) exactly as imdbn_rbm_cd_step does.  apply_wire = unpack_factors(planes_only)
+ * + apply_factors_wire; `planes`: scratch of n_ranks x planes_stride bytes, planes_stride >= imdbn_factor_block's size. */
+int    imdbn_rbm_cd_factors_wire(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B, const imdbn_cd_opts* opts,
+                                 imdbn_rng* rng, int binary_data, void* wire, void* ws, size_t ws_bytes, imdbn_stream_t stream);
+int    imdbn_rbm_apply_wire(const imdbn_rbm_desc* d, const void* wire, size_t wire_stride, int n_ranks, int rows_per_rank,
+                            int global_B, int binary_data, void* planes, size_t planes_stride, const imdbn_cd_opts* opts,
+                            float* loss_out, imdbn_stream_t stream);
 /* apply_factors reading the blocks' head (everything before the visible planes: verbatim in the wire form) straight
  * from the gathered wire blocks and the visible planes from the buffer unpack(planes_only = 1) expanded them into
  * (full-block layout, planes_stride apart): no copy of the 1.9 MB head per rank. */

@@ -1048,16 +1048,13 @@ int imdbn_rbm_gibbs_step(const imdbn_rbm_desc* d, const float* v, int64_t ldv, i
     return c.rng.finish();
 }
 
-int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B, const imdbn_cd_opts* o,
-                      imdbn_rng* rng, float* loss_out, void* ws, size_t ws_bytes, imdbn_stream_t stream) {
-    CHK(check_desc(d, true));
-    if (!data || !o || ldd < d->V) return fail(IMDBN_E_INVALID, "cd_step: bad argument");
+// Start of a CD pass (imdbn_rbm_cd_step, imdbn_rbm_cd_factors_wire): the next batch's preparation (imdbn_cd_opts.next_*) and
+// the prefetch slot the data sit in.  `pn` = the preparation, `rides` = cd_phases carries it on one of its launches.
+static int cd_prologue(Ctx& c, const imdbn_cd_opts* o, PrepArgs& pn, bool& rides, bool allow_compact = true) {
+    const imdbn_rbm_desc* d = c.d;
     if (o->data_slot < 0 || o->data_slot > 2 || (o->next_data && (o->next_slot < 1 || o->next_slot > 2 || o->next_slot == o->data_slot || o->ld_next < d->V)))
-        return fail(IMDBN_E_INVALID, "cd_step: bad prefetch slots (data %d, next %d)", o->data_slot, o->next_slot);
-    Ctx c(d, rng, S(stream));
-    CHK(setup(c, B, ws, ws_bytes));
+        return fail(IMDBN_E_INVALID, "cd: bad prefetch slots (data %d, next %d)", o->data_slot, o->next_slot);
     const int next_rows = (o->next_data && prefetch_available(d)) ? 1 : 0;
-    PrepArgs pn;
     memset(&pn, 0, sizeof(pn));
     if (next_rows > 0) {            // target buffers are taken before the data slot is swapped in
         const Layout& L = c.L;
@@ -1067,21 +1064,32 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
         pn.op.tr = L.pf_tr[t]; pn.op.tr_ts = (int64_t)L.V * L.Bp; pn.op.tr_terms = 3;
         pn.flag = L.pf_flags[t]; pn.colsum_part = L.pf_cs[t];
         pn.op.bits = L.pf_bits[t]; pn.op.bits_shape = 0;
-        if (o->next_binary && vec4_weights(d) && !g_no_k1s && L.Vpad > 1024) {
+        if (allow_compact && o->next_binary && vec4_weights(d) && !g_no_k1s && L.Vpad > 1024) {
             // a 0/1 batch: the positive phase reads the bit plane, the update kernel one bf16 plane (the exactness map says "one term")
             pn.op.rm = nullptr; pn.op.rm_terms = 0; pn.op.tr_terms = 1;
         }
     }
     // Where the next batch is prepared: as extra blocks of the fused K2 (gemm_down_fused_next) or of the negative-phase
     // k1_stream (cd_phases decides); where neither can carry them, a prep_operand launch of its own, first thing.
-    const Layout& L0 = c.L;
-    const bool rides = next_rows > 0 && (!k2s_for_cd(d) || (d->n_groups == 0 && vec4_weights(d) && !g_no_k1s && L0.Vpad > 1024));
+    rides = next_rows > 0 && (!k2s_for_cd(d) || (d->n_groups == 0 && vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024));
     if (next_rows > 0 && !rides) {
         pn.zero = nullptr; pn.n_zero = 0;
         hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(pn.N, pn.op.ldrm), 64), c.L.P), dim3(256), 0, c.s, pn);
         HIPCHK(hipGetLastError());
     }
     if (o->data_slot) { use_slot(c.L, o->data_slot); c.data_prepped = true; }
+    return 0;
+}
+
+int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B, const imdbn_cd_opts* o,
+                      imdbn_rng* rng, float* loss_out, void* ws, size_t ws_bytes, imdbn_stream_t stream) {
+    CHK(check_desc(d, true));
+    if (!data || !o || ldd < d->V) return fail(IMDBN_E_INVALID, "cd_step: bad argument");
+    Ctx c(d, rng, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    PrepArgs pn;
+    bool rides = false;
+    CHK(cd_prologue(c, o, pn, rides));
     CHK(cd_phases(c, data, ldd, o, rides ? &pn : nullptr));
     CHK(c.rng.finish());
     const BiasArgs bias = make_bias(c, o, o->sparsity != 0, (float)B, loss_out);
@@ -1161,6 +1169,8 @@ static FactorWireArgs wire_layout(int V, int H, int B, int binary, size_t* compa
     w.f_vpos = (size_t)((const char*)L.vis_tr[0] - fb);
     w.f_vneg = (size_t)((const char*)L.vis_tr[1] - fb);
     w.f_cs_hpos = (size_t)((const char*)L.cs_hpos - fb);
+    w.f_flags = (size_t)((const char*)L.flags - fb); w.n_flags = (size_t)((const char*)L.hid_tr[0] - (const char*)L.flags);
+    w.f_cs_vpos = (size_t)((const char*)L.cs_vpos - fb); w.n_cs_vpos = (size_t)((const char*)L.cs_vneg - (const char*)L.cs_vpos);
     w.head_bytes = w.f_vpos;                                            // flags .. loss_part precede the visible planes
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t bits = up((size_t)V * L.Bp / 8);
@@ -1177,13 +1187,18 @@ int imdbn_factor_compact_bytes(int V, int H, int B, int binary_data, size_t* byt
     return 0;
 }
 
+// any value >= 1 that changes from call to call (a stale `bad` mark must not match; the caller zero-initialises a fresh compact buffer)
+static int next_pack_epoch() {
+    static std::atomic<int> epoch{0};
+    return epoch.fetch_add(1) % 1000000 + 1;
+}
+
 int imdbn_rbm_pack_factors(int V, int H, int B, int binary_data, const void* block, void* compact, imdbn_stream_t stream) {
     if (V <= 0 || H <= 0 || B <= 0 || !block || !compact || (((uintptr_t)block | (uintptr_t)compact) & 15))
         return fail(IMDBN_E_INVALID, "pack_factors: bad argument (blocks must be 16-B aligned)");
     FactorWireArgs w = wire_layout(V, H, B, binary_data, nullptr);
     w.src = (const char*)block; w.dst = (char*)compact; w.n_ranks = 1;
-    static std::atomic<int> epoch{0};        // any value >= 1 that changes from call to call (a stale `bad` mark must not match;
-    w.epoch = epoch.fetch_add(1) % 1000000 + 1;   //  the caller zero-initialises a fresh compact buffer)
+    w.epoch = next_pack_epoch();
     hipLaunchKernelGGL(factor_pack, dim3(std::min(1024, cdiv((int)(w.head_bytes / 16), 256))), dim3(256), 0, S(stream), w);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1214,6 +1229,31 @@ int imdbn_rbm_cd_factors(const imdbn_rbm_desc* d, const float* data, int64_t ldd
     CHK(setup(c, B, ws, ws_bytes));
     CHK(cd_phases(c, data, ldd, o));
     return c.rng.finish();
+}
+
+// The CD pass of this rank's rows straight into the wire form (cd_factors + pack_factors as one call), with the next-batch
+// preparation of imdbn_rbm_cd_step (imdbn_cd_opts.next_* / data_slot): the data-side factors then sit in a prefetch slot and
+// the pack kernel reads them from there.
+int imdbn_rbm_cd_factors_wire(const imdbn_rbm_desc* d, const float* data, int64_t ldd, int B, const imdbn_cd_opts* o, imdbn_rng* rng,
+                              int binary_data, void* wire, void* ws, size_t ws_bytes, imdbn_stream_t stream) {
+    CHK(check_desc(d, false));
+    if (!data || !o || !wire || ldd < d->V || (((uintptr_t)wire) & 15)) return fail(IMDBN_E_INVALID, "cd_factors_wire: bad argument");
+    if (!factor_mode_ok(d, B, false)) return fail(IMDBN_E_UNSUPPORTED, "cd_factors_wire: needs <= 64 rows per rank, 16-B aligned weight rows, no softmax groups");
+    Ctx c(d, rng, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    PrepArgs pn;
+    bool rides = false;
+    // (a wire form that carries the data as three bf16 planes needs all three written: no compact slot form then)
+    CHK(cd_prologue(c, o, pn, rides, binary_data != 0));
+    CHK(cd_phases(c, data, ldd, o, rides ? &pn : nullptr));
+    CHK(c.rng.finish());
+    FactorWireArgs w = wire_layout(d->V, d->H, B, binary_data, nullptr);
+    w.src = (const char*)ws + c.L.fb_off; w.dst = (char*)wire; w.n_ranks = 1;
+    if (o->data_slot) { w.alt_flags = (const char*)c.L.flags; w.alt_cs_vpos = (const char*)c.L.cs_vpos; w.alt_vpos = (const char*)c.L.vis_tr[0]; }
+    w.epoch = next_pack_epoch();
+    hipLaunchKernelGGL(factor_pack, dim3(std::min(1024, cdiv((int)(w.head_bytes / 16), 256))), dim3(256), 0, c.s, w);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // The update from n_ranks factor blocks.  `head` / `planes`: where the blocks' head (exactness map, hidden planes, column-sum
@@ -1296,6 +1336,14 @@ int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n
 
 int imdbn_rbm_apply_factors_wire(const imdbn_rbm_desc* d, const void* wire, size_t wire_stride, const void* planes, size_t planes_stride,
                                  int n_ranks, int rows_per_rank, int global_B, const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream) {
+    return apply_factors_impl(d, wire, wire_stride, planes, planes_stride, n_ranks, rows_per_rank, global_B, o, loss_out, stream);
+}
+
+// unpack(planes_only) + apply_factors_wire as one call: `planes` = scratch of n_ranks x planes_stride bytes (>= the full block size)
+int imdbn_rbm_apply_wire(const imdbn_rbm_desc* d, const void* wire, size_t wire_stride, int n_ranks, int rows_per_rank, int global_B,
+                         int binary_data, void* planes, size_t planes_stride, const imdbn_cd_opts* o, float* loss_out, imdbn_stream_t stream) {
+    CHK(check_desc(d, true));
+    CHK(imdbn_rbm_unpack_factors(d->V, d->H, rows_per_rank, binary_data, wire, wire_stride, n_ranks, planes, planes_stride, 1, stream));
     return apply_factors_impl(d, wire, wire_stride, planes, planes_stride, n_ranks, rows_per_rank, global_B, o, loss_out, stream);
 }
 

@@ -812,6 +812,10 @@ struct FactorWireArgs {
     int V, Bp, binary;
     int planes_only;                       // unpack: leave the head where it is (the update reads it from the wire blocks)
     int epoch;                             // pack: a value that differs from call to call (no memset of the `bad` word needed)
+    // pack from a workspace whose data-side buffers were swapped for a prefetch slot (imdbn_rbm_cd_factors_wire): the
+    // exactness map, the data's column-sum partials and its planes are then NOT inside the block (nullptr: they are)
+    const char* alt_flags; const char* alt_cs_vpos; const char* alt_vpos;
+    size_t f_flags, n_flags, f_cs_vpos, n_cs_vpos;      // where those two sit in the head, and their (256-B padded) sizes
 };
 
 // byte i of a bit plane <-> the 8 consecutive bf16 elements 8 i .. 8 i + 7 of the plane (one 16-B access per thread: the
@@ -840,19 +844,25 @@ __device__ __forceinline__ uint4 unpack8_bf16(uint32_t w) {
 // non-binary value), word 1 = the epoch itself; the block is bad when the two agree (stale marks of earlier calls do not)
 __global__ __launch_bounds__(256) void factor_pack(const FactorWireArgs a) {
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthr = (int64_t)gridDim.x * 256;
-    for (int64_t i = tid; i < (int64_t)(a.head_bytes / 16); i += nthr)
-        reinterpret_cast<uint4*>(a.dst)[i] = reinterpret_cast<const uint4*>(a.src)[i];
+    for (int64_t i = tid; i < (int64_t)(a.head_bytes / 16); i += nthr) {
+        const size_t o = (size_t)i * 16;
+        const char* from = a.src + o;
+        if (a.alt_flags && o >= a.f_flags && o < a.f_flags + a.n_flags) from = a.alt_flags + (o - a.f_flags);
+        if (a.alt_cs_vpos && o >= a.f_cs_vpos && o < a.f_cs_vpos + a.n_cs_vpos) from = a.alt_cs_vpos + (o - a.f_cs_vpos);
+        reinterpret_cast<uint4*>(a.dst)[i] = *reinterpret_cast<const uint4*>(from);
+    }
     const int64_t nb = (int64_t)a.V * a.Bp / 8;                       // bytes of a bit plane
+    const char* vpos = a.alt_vpos ? a.alt_vpos : a.src + a.f_vpos;
     bool bad = false;
     for (int64_t i = tid; i < nb; i += nthr)
         reinterpret_cast<uint8_t*>(a.dst + a.c_vneg)[i] = (uint8_t)pack8_bf16(reinterpret_cast<const uint4*>(a.src + a.f_vneg)[i], bad);
     if (a.binary) {
         for (int64_t i = tid; i < nb; i += nthr)
-            reinterpret_cast<uint8_t*>(a.dst + a.c_vpos)[i] = (uint8_t)pack8_bf16(reinterpret_cast<const uint4*>(a.src + a.f_vpos)[i], bad);
+            reinterpret_cast<uint8_t*>(a.dst + a.c_vpos)[i] = (uint8_t)pack8_bf16(reinterpret_cast<const uint4*>(vpos)[i], bad);
     } else {
         const int64_t n16 = (int64_t)3 * a.V * a.Bp * 2 / 16;
         for (int64_t i = tid; i < n16; i += nthr)
-            reinterpret_cast<uint4*>(a.dst + a.c_vpos)[i] = reinterpret_cast<const uint4*>(a.src + a.f_vpos)[i];
+            reinterpret_cast<uint4*>(a.dst + a.c_vpos)[i] = reinterpret_cast<const uint4*>(vpos)[i];
     }
     if (bad) *reinterpret_cast<volatile int*>(a.dst + a.c_bad) = a.epoch;
     if (tid == 0) reinterpret_cast<volatile int*>(a.dst + a.c_bad)[1] = a.epoch;

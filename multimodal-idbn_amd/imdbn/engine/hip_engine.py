@@ -304,6 +304,22 @@ class HipEngine:
             ok = self._pf_ok[key] = bool(self._lib.imdbn_rbm_prefetch_ok(C.byref(d), B))
         return ok
 
+    def _prefetch_opts(self, o, d, x, next_data):
+        """Fill the next-batch fields of the options of a CD pass on batch `x` (imdbn_cd_opts.next_* / data_slot); returns the
+        key of the prefetch state and the accepted hint (None: none) -- the caller records ``self._pf[key]`` after the call."""
+        B, dev = x.size(0), x.device
+        key = (dev, d.V, d.H, B, torch.cuda.current_stream(dev).cuda_stream)
+        st = self._pf.pop(key, None)
+        if st is not None and st[0] == self._ident(x):
+            o.data_slot = st[1]
+        nxt = None
+        if (next_data is not None and next_data.dtype == torch.float32 and next_data.device == dev and next_data.dim() == 2
+                and tuple(next_data.shape) == tuple(x.shape) and next_data.stride(1) == 1 and self.prefetch_ok(d, B)):
+            nxt = next_data
+            o.next_data, o.ld_next, o.next_slot = nxt.data_ptr(), nxt.stride(0), (2 if o.data_slot == 1 else 1)
+            o.next_binary = int(self.data_is_binary(next_data))
+        return key, nxt
+
     def cd_step(self, rbm, data, lr, mom, cd_k, rng, next_data=None, data_binary=None, forward=False):
         """One CD-k update.  ``next_data``: the batch the NEXT cd_step of this shape will get -- its operand forms are
         then prepared by extra blocks of this call's first negative-phase launch and the
@@ -318,16 +334,7 @@ class HipEngine:
         r, keep = self._rng(rng, sched, B, dev)
         loss = torch.empty(1, device=dev)
         ws = self._workspace(dev, d.V, d.H, B)
-        key = (dev, d.V, d.H, B, torch.cuda.current_stream(dev).cuda_stream)
-        st = self._pf.pop(key, None)
-        if st is not None and st[0] == self._ident(x):
-            o.data_slot = st[1]
-        nxt = None
-        if (next_data is not None and next_data.dtype == torch.float32 and next_data.device == dev and next_data.dim() == 2
-                and tuple(next_data.shape) == tuple(x.shape) and next_data.stride(1) == 1 and self.prefetch_ok(d, B)):
-            nxt = next_data
-            o.next_data, o.ld_next, o.next_slot = nxt.data_ptr(), nxt.stride(0), (2 if o.data_slot == 1 else 1)
-            o.next_binary = int(self.data_is_binary(next_data))
+        key, nxt = self._prefetch_opts(o, d, x, next_data)
         fwd = None
         if forward:
             fwd = torch.empty(B, d.H, device=dev)
@@ -434,6 +441,40 @@ class HipEngine:
         self._done(rng, r, sched)
         off, nb = self.factor_block(d.V, d.H, B)
         return ws[off:off + nb]
+
+    def cd_factors_wire(self, rbm, data, cd_k, rng, binary: bool, next_data=None, data_binary=None) -> torch.Tensor:
+        """The CD pass of this rank's rows straight into the wire form of its factor block (imdbn_rbm_cd_factors_wire =
+        cd_factors + pack_factors in one call), with the next-batch hint of ``cd_step``.  Returns a reusable buffer."""
+        d = self._desc(rbm, True)       # (imdbn_rbm_prefetch_ok wants the full descriptor)
+        x = _f32c(data, "data")
+        B, dev = x.size(0), x.device
+        o = self._opts(rbm, 0.0, 0.0, cd_k)
+        o.data_binary = int(self.data_is_binary(data) if data_binary is None else bool(data_binary))
+        sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
+        r, keep = self._rng(rng, sched, B, dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        key, nxt = self._prefetch_opts(o, d, x, next_data)
+        out = self._wire_buffer("wire1", rbm, B, 1, binary)[0]
+        N.check(self._lib.imdbn_rbm_cd_factors_wire(C.byref(d), _ptr(x), x.stride(0), B, C.byref(o), C.byref(r), int(bool(binary)), _ptr(out),
+                                                     _ptr(ws), ws.numel(), self._stream(dev)), "imdbn_rbm_cd_factors_wire")
+        self._done(rng, r, sched)
+        if nxt is not None:
+            self._pf[key] = (self._ident(nxt), int(o.next_slot), nxt)
+        return out
+
+    def apply_wire(self, rbm, wires: torch.Tensor, rows_per_rank, global_B, binary: bool, lr, mom):
+        """The update from the gathered wire blocks (imdbn_rbm_apply_wire = unpack_factors(planes_only) + apply_factors_wire)."""
+        d = self._desc(rbm, True)
+        dev = wires.device
+        world = int(wires.size(0))
+        assert wires.dtype == torch.uint8 and wires.dim() == 2 and wires.is_contiguous()
+        planes = self.gather_buffer(rbm, rows_per_rank, world)
+        o = self._opts(rbm, lr, mom, 1, sparsity=getattr(rbm, "sparsity", False))
+        loss = torch.empty(1, device=dev)
+        N.check(self._lib.imdbn_rbm_apply_wire(C.byref(d), _ptr(wires), int(wires.stride(0)), world, int(rows_per_rank), int(global_B),
+                                                int(bool(binary)), _ptr(planes), int(planes.stride(0)), C.byref(o), _ptr(loss),
+                                                self._stream(dev)), "imdbn_rbm_apply_wire")
+        return loss.reshape(())
 
     def gather_buffer(self, rbm, B, world) -> torch.Tensor:
         """Reusable [world, block bytes] uint8 buffer for the all-gather of the factor blocks."""

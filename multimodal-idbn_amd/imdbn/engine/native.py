@@ -82,6 +82,8 @@ SIGNATURES = {
     "imdbn_factor_compact_bytes": (_INT, [_INT, _INT, _INT, _INT, C.POINTER(_SZ)]),
     "imdbn_rbm_pack_factors": (_INT, [_INT, _INT, _INT, _INT, _P, _P, _P]),
     "imdbn_rbm_unpack_factors": (_INT, [_INT, _INT, _INT, _INT, _P, _SZ, _INT, _P, _SZ, _INT, _P]),
+    "imdbn_rbm_cd_factors_wire": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _INT, _P, _P, _SZ, _P]),
+    "imdbn_rbm_apply_wire": (_INT, [C.POINTER(RbmDesc), _P, _SZ, _INT, _INT, _INT, _INT, _P, _SZ, C.POINTER(CdOpts), _P, _P]),
     "imdbn_rbm_apply_factors_wire": (_INT, [C.POINTER(RbmDesc), _P, _SZ, _P, _SZ, _INT, _INT, _INT, C.POINTER(CdOpts), _P, _P]),
     "imdbn_rbm_cd_stats": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
     "imdbn_rbm_apply_delta": (_INT, [C.POINTER(RbmDesc), _P, _INT, C.POINTER(CdOpts), _P, _P]),

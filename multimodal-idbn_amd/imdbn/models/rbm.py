@@ -207,7 +207,13 @@ class RBM(nn.Module):
             dp.validate_rows(B, x.device)
             ret = (lambda loss: (loss, self.forward(data))) if return_forward else (lambda loss: loss)
             if dp.mode() == "factors" and hasattr(eng, "factor_mode_ok") and eng.factor_mode_ok(self, B):
-                # exchange the factors (~7 MB per rank at 10000 x 1500) instead of the fp32 statistics (60 MB)
+                # exchange the factors (~7 MB per rank at 10000 x 1500; 2 MB in wire form) instead of the fp32 statistics (60 MB)
+                if hasattr(eng, "cd_factors_wire"):
+                    # three calls per step: CD pass into the wire form (with the next-batch hint), all-gather, update
+                    binary = dp.binary_data()
+                    wire = eng.cd_factors_wire(self, x, CD, rng, binary, next_data=next_data, **kw)
+                    wires = dp.all_gather_blocks(eng.compact_gather_buffer(self, B, dp.world_size(), binary), wire)
+                    return ret(eng.apply_wire(self, wires, B, B * dp.world_size(), binary, lr, mom))
                 block = eng.cd_factors(self, x, CD, rng, **kw)
                 if hasattr(eng, "pack_factors"):
                     # wire form: the visible planes as bits (the sample always, the data when declared binary)

@@ -658,6 +658,50 @@ def test_factor_wire_form_round_trips_and_poisons_on_a_false_promise(binary, _na
         assert torch.isnan(rd.hid_bias.data).any()
 
 
+@pytest.mark.parametrize("V,H,B,binary", [(2048, 512, 40, True), (2048, 512, 40, False), (10000, 1500, 64, True)])
+def test_fused_dp_halves_equal_the_separate_calls(V, H, B, binary, _native):
+    """imdbn_rbm_cd_factors_wire (CD pass + pack, with the next-batch hint) and imdbn_rbm_apply_wire (unpack + update) against
+    cd_factors / pack_factors / unpack_factors / apply_factors_wire: two emulated ranks, four steps, the hint naming the batch
+    of the following CD pass (so the data-side factors are packed from a prefetch slot): same wire blocks, same weights."""
+    from imdbn import engine as E
+    R, T = 2, 4
+    g = np.random.default_rng(V + B)
+    mk = lambda: P.T((g.random((B, V), dtype=F32) > 0.7).astype(F32), DEV)
+    Xs = [[mk() for _ in range(R)] for _ in range(T)]
+    if not binary:
+        Xs[2][1] = P.T(g.random((B, V), dtype=F32), DEV)                # an inexact batch: three-term planes on the wire
+    seq = [Xs[t][k] for t in range(T) for k in range(R)]
+    ra, _, _ = _mk(V, H, None, seed=2)
+    rb, _, _ = _mk(V, H, None, seed=2)
+    rng_a = [E.PhiloxRng(seed=9, row0=k * B) for k in range(R)]
+    rng_b = [E.PhiloxRng(seed=9, row0=k * B) for k in range(R)]
+    used_slot = 0
+    for t in range(T):
+        wa = []
+        for k in range(R):
+            blk = _native.cd_factors(ra, Xs[t][k], 1, rng_a[k])
+            wa.append(_native.pack_factors(ra, blk, B, binary).clone())
+        wa = torch.stack(wa)
+        la = _native.apply_factors_wire(ra, wa, _native.unpack_factors(ra, wa, B, binary, planes_only=True), B, B * R, 0.1, 0.5)
+        wb = []
+        for k in range(R):
+            i = t * R + k
+            nxt = seq[i + 1] if i + 1 < len(seq) else None
+            before = len(_native._pf)
+            wb.append(_native.cd_factors_wire(rb, Xs[t][k], 1, rng_b[k], binary, next_data=nxt).clone())
+            used_slot += before
+        wb = torch.stack(wb)
+        assert torch.equal(wa[:, : wa.size(1) - 256], wb[:, : wb.size(1) - 256]), f"wire blocks differ at step {t}"   # (trailer = pack epoch)
+        lb = _native.apply_wire(rb, wb, B, B * R, binary, 0.1, 0.5)
+        assert float(la) == float(lb)
+        for k in P.KEYS:
+            ta, tb = getattr(ra, k), getattr(rb, k)
+            assert torch.equal(ta.data if hasattr(ta, "data") else ta, tb.data if hasattr(tb, "data") else tb), (k, t)
+    if _native.prefetch_ok(_native._desc(rb, True), B):
+        assert used_slot >= T * R - 1              # the hints were taken: the passes after the first read a prefetch slot
+    _native._pf.clear()
+
+
 @pytest.mark.parametrize("V,H,B,rows,kernel", [
     (545, 380, 127, 24, "old"), (20, 468, 95, 24, "old"), (982, 24, 52, 28, "old"), (545, 64, 33, 20, "old"),
     (5511, 64, 33, 0, "old"), (6301, 36, 20, 0, "old"), (4500, 40, 70, 0, "old"),

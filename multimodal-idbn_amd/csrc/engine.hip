@@ -758,6 +758,7 @@ int run_chain_k4(Ctx& c, const float* vk, const float* mask, int64_t ldk, int n_
     a.vk = vk; a.mask = mask; a.ldk = ldk;
     // rows per block: enough blocks to spread the per-element work (Philox, Box-Muller, sigmoid) over the CUs;
     // one block per CU at most (every block streams all of W from L2)
+    a.dbg = (g_dbg & 1024) ? 1 : 0;
     a.rows = g_k4_rows > 0 ? g_k4_rows : (B <= 2 * cu_count() ? 2 : (B <= 4 * cu_count() ? 4 : (B <= 8 * cu_count() ? 8 : 16)));      // measured: 0.90 / 0.99 / 1.19 / 1.59 ms for 2 / 4 / 8 / 16 rows (30 steps, 532<->256)
     if (c.nw == 3) hipLaunchKernelGGL(k4_chain<2>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);      // PARITY: fp16 hi + lo terms
     else           hipLaunchKernelGGL(k4_chain<1>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);

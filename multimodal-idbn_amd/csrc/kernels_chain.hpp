@@ -108,6 +108,7 @@ struct K4Args {
     uint64_t seed; int64_t row0;
     const float* mu; int64_t ldmu; int Dz;
     const float* vk; const float* mask; int64_t ldk;
+    int dbg;                                       // 1: per-block stamps of chain step 2 (tools/stamps_probe.py)
 };
 
 __device__ __forceinline__ DrawSrc k4_src(const K4Args& a, const ChainDraw& d, int N) {
@@ -132,7 +133,7 @@ __device__ __forceinline__ void k4_put(bf16_t* act, int AK, int row, int col, fl
 // rows 4*(l>>4)+r) at the end of each tile.
 // NW / NA are compile-time: a run-time `if (tw < nw)` puts a branch around every load and MFMA and the compiler then
 // waits vmcnt(0) before each MFMA (no overlap at all).
-constexpr int K4_RING = 6;
+constexpr int K4_RING = 6;           // 12 was tried in round 2: the ring then spills (96 B/lane) and the GEMM phases go 7.5 -> 8.7 us
 template <int NW, int NA>
 __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB, const bf16_t* act, int AK,
                                         float* stage, int SP) {
@@ -219,6 +220,8 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     const int RP = (RB + 1) / 2;                                  // row pairs of the block
     for (int t = 0; t < a.n_steps; ++t) {
         const ChainRec r = a.recs[t];
+        const bool st = a.dbg && t == 2;
+        stamp(st, blockIdx.x, 0);
         const bool sample_h = (r.flags & 1) != 0, clamp = (r.flags & 8) != 0, last = t == a.n_steps - 1;
         const int vmode = (r.flags >> 1) & 3;
         const float T = fmaxf(r.T, 1e-6f);                       // max(1e-6, T)  rbm.py:92,96
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
         // ---- h | v  (rbm.py:81-92) -----------------------------------------------------------------
         k4_gemm<NW, NW>(a, 0, NTu, KBu, vact, VK, stage, SP);
         __syncthreads();
+        stamp(st, blockIdx.x, 1);
         {
             const DrawSrc nz = k4_src(a, r.noise_h, a.H), un = k4_src(a, r.uni_h, a.H);
             // thread = (row pair, column): the pair's draws come from one Philox block each (common.hpp)
@@ -248,10 +252,12 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
             }
         }
         __syncthreads();
+        stamp(st, blockIdx.x, 2);
         // ---- v | h  (rbm.py:94-135) ------------------------------------------------------------------
         if (sample_h) k4_gemm<NW, 1>(a, 1, NTd, KBd, hact, HK, stage, SP);      // sampled states are exactly bf16: one term
         else          k4_gemm<NW, NW>(a, 1, NTd, KBd, hact, HK, stage, SP);
         __syncthreads();
+        stamp(st, blockIdx.x, 3);
         {
             const DrawSrc nz = k4_src(a, r.noise_v, a.V), un = k4_src(a, r.uni_v, a.V);
             for (int i = tid; i < RP * a.V; i += K4_THREADS) {
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                 }
             }
         }
+        stamp(st, blockIdx.x, 4);
         if (gwd > 0) {
             // softmax + categorical of the group (finish_groups_body arithmetic).  The exponentials and the clipped
             // probabilities are computed by all threads; only the ORDERED sums (softmax denominator, inverse-CDF
@@ -401,6 +408,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
             }
         }
         __syncthreads();
+        stamp(st, blockIdx.x, 5);
     }
 }
 

@@ -558,6 +558,66 @@ def case_pretrained_finetune():
          yi=yi.astype(np.int32), losses=np.array(losses, np.float32), **out)
 
 
+def case_probe():
+    """Evaluation side-car: the reference's imdbn/utils/probe_utils.py run as it is on a stub model
+    (a fixed tanh map as `represent`, a list of batches as `val_loader`): binning, stratified split, the AdamW linear probe
+    with early stopping and the confusion matrices its log_linear_probe writes as CSV.  Uses torch's own generator for the
+    nn.Linear initialisation (re-seeded per call below, so the fixture does not depend on the order of the cases)."""
+    import importlib.util as ilu
+    import pandas as pd
+    sp = ilu.spec_from_file_location("ref_probe_utils", "/root/reference/imdbn/utils/probe_utils.py")
+    RP = ilu.module_from_spec(sp)
+    sp.loader.exec_module(RP)
+    g = np.random.Generator(np.random.PCG64(77))
+    N, Din, D = 360, 48, 24
+    lab = g.integers(0, 6, N)
+    X = (g.random((N, Din)) < (0.15 + 0.1 * lab[:, None] * (np.arange(Din)[None, :] % 6 == lab[:, None]))).astype(np.float32)
+    A = (g.standard_normal((Din, D)) / np.sqrt(Din)).astype(np.float32)
+    cum_area = (X.sum(1) + 0.25 * g.standard_normal(N)).astype(np.float32)
+    chull = np.round(X[:, ::3].sum(1)).astype(np.float32)                  # discrete, many ties: exercises the equal-edge rule
+    density = (lab + g.random(N)).astype(np.float32)
+
+    class Stub:
+        pass
+    m = Stub()
+    m.device = torch.device("cpu"); m.text_flag = False; m.wandb_run = None
+    m.arch_dir = tempfile.mkdtemp(prefix="probe_ref_")
+    Xt = torch.from_numpy(X)
+    m.val_loader = [(Xt[i:i + 100], torch.zeros(len(Xt[i:i + 100]), 1)) for i in range(0, N, 100)]
+    m.represent = lambda x, upto_layer=None: torch.tanh(x @ torch.from_numpy(A))
+    m.features = {"Cumulative Area": torch.from_numpy(cum_area), "Convex Hull": torch.from_numpy(chull),
+                  "Labels": torch.nn.functional.one_hot(torch.from_numpy(lab), 6).float(), "Density": torch.from_numpy(density)}
+    E, feats = RP.compute_val_embeddings_and_features(m)
+    out = dict(X=X, A=A, lab=lab.astype(np.int64), cum_area=cum_area, chull=chull, density=density, E=E.numpy())
+    n_bins, steps, seed0 = 4, 200, 4321
+    names = {}
+    for mkey in ("cum_area", "convex_hull", "labels", "density"):
+        y, nc, edges, bin_names = RP._prepare_targets(feats, mkey, n_bins)
+        tr, te = RP.stratified_split(y, test_size=0.2, rng_seed=42)
+        out[f"{mkey}_y"] = y.numpy(); out[f"{mkey}_edges"] = edges.numpy()
+        out[f"{mkey}_train_idx"] = np.array(tr, np.int64); out[f"{mkey}_test_idx"] = np.array(te, np.int64)
+        names[mkey] = bin_names
+        # the classifier alone, from a known generator state (its nn.Linear draws from torch's global generator)
+        torch.manual_seed(seed0)
+        acc, yt, yp = RP.train_linear_classifier(E.numpy()[tr], y.numpy()[tr], E.numpy()[te], y.numpy()[te], m.device, nc,
+                                                 max_steps=steps, lr=1e-2, weight_decay=0.01, patience=15, min_delta=0.0)
+        out[f"{mkey}_acc"] = np.float64(acc); out[f"{mkey}_y_true"] = np.array(yt, np.int64); out[f"{mkey}_y_pred"] = np.array(yp, np.int64)
+    # the orchestrator end to end: confusion matrices from the CSV files it writes
+    torch.manual_seed(seed0)
+    RP.log_linear_probe(m, epoch=3, n_bins=n_bins, steps=steps, lr=1e-2, patience=15, save_csv=True, layer_tag="top")
+    for mkey in ("cum_area", "convex_hull", "labels", "density"):
+        df = pd.read_csv(os.path.join(m.arch_dir, f"probe_top_{mkey}_confusion_epoch3.csv"), index_col=0)
+        out[f"{mkey}_confusion"] = df.to_numpy().astype(np.int64)
+        assert [str(c) for c in df.columns] == names[mkey]
+    save("probe_reference_360.npz",
+         dict(case="probe", n_bins=n_bins, steps=steps, seed=seed0, patience=15, weight_decay_direct=0.01, bin_names=names, min_margin=None,
+              recipe="stub model: represent = tanh(x @ A), val_loader = 4 batches; reference compute_val_embeddings_and_features, "
+                     "_prepare_targets, stratified_split(0.2, 42), train_linear_classifier after torch.manual_seed(seed) "
+                     "(max_steps=steps, lr=1e-2, wd=0.01, patience=15), log_linear_probe(epoch=3, layer_tag='top') after "
+                     "torch.manual_seed(seed): confusion matrices read back from its CSV files"),
+         **out)
+
+
 if __name__ == "__main__":
     # torch.multinomial draws from torch's global generator (seeded above): the recorded categorical indices -- and with them
     # every later number -- depend on the ORDER of the cases; regenerate with all cases in this order ("pretrained" last)
@@ -569,3 +629,4 @@ if __name__ == "__main__":
     if "bimodal" in which: case_bimodal_small()
     if "c2" in which: case_c2_digest()
     if "pretrained" in which: case_pretrained_finetune()
+    if "probe" in which: case_probe()          # order-independent (re-seeds torch itself); not part of the default list

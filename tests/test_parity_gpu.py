@@ -470,6 +470,13 @@ def test_dp_path_over_rccl_world1_equals_fused_update():
     assert abs(float(l1) - float(l2)) < 1e-6
 
 
+def test_probe_side_car_on_the_device_matches_the_reference_run(tmp_path):
+    """tests/golden/probe_reference_360.npz (the reference's own probe_utils.py on a stub model): binning, split and bin names
+    exactly; the device-resident AdamW probe within 3 % of the reference's predictions (fp32 matmul order differs on the GPU)."""
+    from test_probe_utils_cpu import check_probe_against_reference_fixture
+    check_probe_against_reference_fixture(torch.device(DEV), tmp_path, min_same=0.97)
+
+
 def test_probe_side_car_stays_on_the_device():
     """Evaluation side-car: validation embeddings come from the engine and stay in HBM, the
     linear probe runs there and agrees with its CPU run on the same inputs."""

@@ -125,3 +125,64 @@ def test_probes_run_on_engine_embeddings(tmp_path, monkeypatch):
             PU.compute_joint_embeddings_and_features(mdl)
     finally:
         E.set_engine_for_testing(None)
+
+
+# ---- pinned by the reference: tests/golden/probe_reference_360.npz (make_fixtures.py case_probe ran the reference's own
+# ---- imdbn/utils/probe_utils.py on a stub model) ------------------------------------------------------------------------
+def _probe_fixture():
+    import json, os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "probe_reference_360.npz"), allow_pickle=False)
+    return fx, json.loads(str(fx["meta"]))
+
+
+class _StubModel:
+    """What the fixture's generator handed the reference: a fixed tanh map as `represent`, four batches as the loader."""
+    def __init__(self, fx, device, arch_dir):
+        X, A = torch.from_numpy(fx["X"]).to(device), torch.from_numpy(fx["A"]).to(device)
+        self.device, self.text_flag, self.wandb_run, self.arch_dir = device, False, None, str(arch_dir)
+        self.val_loader = [(X[i:i + 100], torch.zeros(len(X[i:i + 100]), 1)) for i in range(0, len(X), 100)]
+        self.represent = lambda x, upto_layer=None: torch.tanh(x @ A)
+        self.features = {"Cumulative Area": torch.from_numpy(fx["cum_area"]), "Convex Hull": torch.from_numpy(fx["chull"]),
+                         "Labels": torch.nn.functional.one_hot(torch.from_numpy(fx["lab"]), 6).float(),
+                         "Density": torch.from_numpy(fx["density"])}
+
+
+def check_probe_against_reference_fixture(device, tmp_path, min_same=1.0):
+    fx, meta = _probe_fixture()
+    m = _StubModel(fx, device, tmp_path)
+    E_, feats = PU.compute_val_embeddings_and_features(m)
+    np.testing.assert_allclose(E_.cpu().numpy(), fx["E"], rtol=1e-5, atol=1e-6)
+    assert sorted(feats) == ["convex_hull", "cum_area", "density", "labels"]
+    for mkey in ("cum_area", "convex_hull", "labels", "density"):
+        y, nc, edges, names = PU._prepare_targets(feats, mkey, meta["n_bins"])
+        assert nc == meta["n_bins"] and names == meta["bin_names"][mkey]
+        assert np.array_equal(y.cpu().numpy(), fx[f"{mkey}_y"])
+        np.testing.assert_allclose(edges.cpu().numpy(), fx[f"{mkey}_edges"], rtol=0, atol=1e-6)
+        tr, te = PU.stratified_split(y, test_size=0.2, rng_seed=42)
+        assert np.array_equal(np.array(tr), fx[f"{mkey}_train_idx"]) and np.array_equal(np.array(te), fx[f"{mkey}_test_idx"])
+        torch.manual_seed(meta["seed"])                      # the nn.Linear initialisation comes from torch's generator
+        Ef = torch.from_numpy(fx["E"]).to(device)
+        acc, yt, yp = PU.train_linear_classifier(Ef[tr], y[tr], Ef[te], y[te], device, nc, max_steps=meta["steps"], lr=1e-2,
+                                                 weight_decay=meta["weight_decay_direct"], patience=meta["patience"], min_delta=0.0)
+        assert yt == fx[f"{mkey}_y_true"].tolist()
+        same = float(np.mean(np.array(yp) == fx[f"{mkey}_y_pred"]))
+        assert same >= min_same, (mkey, same)
+        assert abs(acc - float(fx[f"{mkey}_acc"])) <= (1.0 - min_same) + 1e-6, (mkey, acc, float(fx[f"{mkey}_acc"]))
+    # the orchestrator end to end: the confusion matrices the reference wrote as CSV
+    torch.manual_seed(meta["seed"])
+    res = PU.log_linear_probe(m, epoch=3, n_bins=meta["n_bins"], steps=meta["steps"], lr=1e-2, patience=meta["patience"],
+                              save_csv=True, layer_tag="top")
+    for mkey in ("cum_area", "convex_hull", "labels", "density"):
+        cm = res[f"top/{mkey}"]["confusion"].numpy()
+        want = fx[f"{mkey}_confusion"]
+        assert cm.sum() == want.sum() and np.abs(cm - want).sum() <= 2 * round((1.0 - min_same) * want.sum()), (mkey, cm, want)
+        import pandas as pd
+        df = pd.read_csv(res[f"top/{mkey}"]["csv"], index_col=0)            # same file name and layout as the reference's CSV
+        assert [str(c) for c in df.columns] == meta["bin_names"][mkey] and np.array_equal(df.to_numpy(), cm)
+        assert res[f"top/{mkey}"]["csv"].endswith(f"probe_top_{mkey}_confusion_epoch3.csv")
+
+
+def test_probe_side_car_reproduces_the_reference_run(tmp_path):
+    """Binning, stratified split, the AdamW probe with early stopping and the confusion matrices equal what the reference's
+    own probe_utils.py produced on the same stub model (CPU: same generator, same arithmetic order -> identical predictions)."""
+    check_probe_against_reference_fixture(torch.device("cpu"), tmp_path, min_same=1.0)

@@ -6,6 +6,9 @@ constructor and ``_build_joint`` (:437-575), ``load_pretrained_mod{1,2}_dbn`` (:
 ``train_joint`` batch loop with its online cross-modal MSE (:711-826), ``save_model`` / ``load_model`` (:1017-1076).
 The wandb / PCA / probe / trajectory / snapshot tail (:828-1015) is the observability side-car and is out of scope.
 
+Data parallelism (``imdbn.engine.dp``): the RBM updates shard by rows themselves; the two host-side accumulators here (the
+bias-initialisation counters and the per-epoch cross-modal MSE sums) are all-reduced once each, as in ``iMDBN``.
+
 Only orchestration lives here: every RBM operation (CD-k, clamped CD-3 with sampled hidden units, the noisy
 mean-field and Gibbs chains, propagations) is one engine call.
 """
@@ -19,6 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from imdbn import engine as _E
 from imdbn.models.idbn import iDBN
 from imdbn.models.rbm import RBM
 from imdbn.utils import batches
@@ -143,6 +147,14 @@ class iMDBN_BiModal(nn.Module):
             sum_z1 = z1.sum(0) if sum_z1 is None else (sum_z1 + z1.sum(0))
             sum_z2 = z2.sum(0) if sum_z2 is None else (sum_z2 + z2.sum(0))
             n += z1.size(0)
+        if _E.dp.active():
+            # every rank saw its own shard of the first batches: the counters are sums over rows
+            D1, D2 = self.Dz_mod1, self.Dz_mod2
+            pack = torch.cat([(sum_z1 if sum_z1 is not None else torch.zeros(D1, device=self.device)).double(),
+                              (sum_z2 if sum_z2 is not None else torch.zeros(D2, device=self.device)).double(),
+                              torch.tensor([float(n)], device=self.device, dtype=torch.float64)])
+            _E.dp.all_reduce_sum(pack)
+            sum_z1, sum_z2, n = pack[:D1].float(), pack[D1:D1 + D2].float(), int(round(float(pack[D1 + D2])))
         if n == 0:
             return
         mean_z1 = (sum_z1 / n).clamp(1e-4, 1 - 1e-4)
@@ -230,6 +242,8 @@ class iMDBN_BiModal(nn.Module):
                     acc[0] += B
                     acc[1] += F.mse_loss(r1.view_as(v1), v1, reduction="sum").double()
                     acc[2] += F.mse_loss(r2.view_as(v2), v2, reduction="sum").double()
+            if _E.dp.active():                      # each rank accumulated its shard: sums over rows
+                _E.dp.all_reduce_sum(acc)
             n, s1, s2 = (float(x) for x in acc.tolist())                            # one host sync per epoch
             npix1, npix2 = self.mod1_dbn.layers[0].num_visible, self.mod2_dbn.layers[0].num_visible
             self.joint_history.append({

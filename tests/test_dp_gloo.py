@@ -232,3 +232,93 @@ def test_uneven_shards_raise_on_every_rank_instead_of_hanging(tmp_path):
         row0, msg = open(tmp_path / f"ragged{rank}.txt").read().split("|", 1)
         assert "between 5 and 8 rows" in msg, msg
         assert int(row0) == 0
+
+
+# ---- iMDBN_BiModal under data parallelism (missing item 7; imdbn_bimodal.py:741-829) ----------------
+BM_S1, BM_S2, BM_J, BM_B, BM_NB, BM_EPOCHS = [48, 20], [36, 16], [14, 10], 16, 2, 9       # 9 epochs: crosses the 8-epoch warm-up
+
+
+def _make_bimodal(rank=None, world=1):
+    from imdbn.models import iMDBN_BiModal
+    from torch.utils.data import DataLoader, TensorDataset
+    g = np.random.Generator(np.random.PCG64(23))
+    n = BM_B * BM_NB
+    yi = np.arange(n) % 4
+    X1 = np.abs((g.random((4, BM_S1[0])) > 0.6).astype(np.float32)[yi] - (g.random((n, BM_S1[0])) > 0.9)).astype(np.float32)
+    X2 = np.abs((g.random((4, BM_S2[0])) > 0.6).astype(np.float32)[yi] - (g.random((n, BM_S2[0])) > 0.9)).astype(np.float32)
+    Ws = [(g.standard_normal((a, b)) / np.sqrt(a)).astype(np.float32)
+          for a, b in ((BM_S1[0], BM_S1[1]), (BM_S2[0], BM_S2[1]), (BM_S1[1] + BM_S2[1], BM_J[0]), (BM_J[0], BM_J[1]))]
+    per = BM_B // world
+    if rank is not None:
+        rows = np.concatenate([np.arange(b * BM_B + rank * per, b * BM_B + (rank + 1) * per) for b in range(BM_NB)])
+        X1, X2 = X1[rows], X2[rows]
+    dl = DataLoader(TensorDataset(torch.from_numpy(X1), torch.from_numpy(X2)), batch_size=per if rank is not None else BM_B, shuffle=False)
+    params = {"LEARNING_RATE": 0.1, "WEIGHT_PENALTY": 1e-4, "INIT_MOMENTUM": 0.5, "FINAL_MOMENTUM": 0.95, "LEARNING_RATE_DYNAMIC": True,
+              "CD": 1, "JOINT_CD": 1, "CROSS_GIBBS_STEPS": 4, "JOINT_AUX_COND_STEPS": 10, "JOINT_LEARNING_RATE": 0.05}
+    mdl = iMDBN_BiModal(BM_S1, BM_S2, BM_J, params=params, dataloader=dl, val_loader=dl, device=torch.device("cpu"))
+    for r, W in zip([mdl.mod1_dbn.layers[0], mdl.mod2_dbn.layers[0], *mdl.joint_layers], Ws):
+        r.W.data = torch.from_numpy(W.copy())
+        r.W_m, r.hb_m, r.vb_m = torch.zeros_like(r.W.data), torch.zeros_like(r.hid_bias.data), torch.zeros_like(r.vis_bias.data)
+    return mdl
+
+
+def _bimodal_state(mdl):
+    out = {}
+    for i, r in enumerate(mdl.joint_layers):
+        out.update({f"W{i}": r.W.data.numpy(), f"hb{i}": r.hid_bias.data.numpy(), f"vb{i}": r.vis_bias.data.numpy(), f"Wm{i}": r.W_m.numpy()})
+    h = mdl.joint_history
+    out["mse1"] = np.array([r["mod1_mse"] for r in h]); out["mse2"] = np.array([r["mod2_mse"] for r in h])
+    out["cd"] = np.concatenate([r["cd_losses"].numpy() for r in h if r["cd_losses"] is not None])
+    return out
+
+
+def _bimodal_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from imdbn import engine as E
+    from oracle_engine import OracleEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir(out_dir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E.set_engine_for_testing(OracleEngine())
+    E.dp.enable(mode="allreduce")
+    mdl = _make_bimodal(rank, world)
+    E.set_rng(E.PhiloxRng(SEED))
+    mdl.train_joint(BM_EPOCHS)
+    np.savez(os.path.join(out_dir, f"bimodal_rank{rank}.npz"), **_bimodal_state(mdl))
+    dist.destroy_process_group()
+
+
+def test_two_rank_bimodal_train_joint_equals_single_rank(tmp_path, monkeypatch):
+    """iMDBN_BiModal.train_joint on two ranks (half batches each): the clamped CD-3 warm-up, the per-layer CD through the joint
+    stack, the bias-initialisation counters and the per-epoch cross-modal MSE sums end at the single-process run."""
+    import socket
+    import torch.multiprocessing as mp
+    from imdbn import engine as E
+    from oracle_engine import OracleEngine
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, PKG, HERE, os.environ.get("PYTHONPATH", "")])
+    mp.spawn(_bimodal_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    monkeypatch.chdir(tmp_path)
+    E.set_engine_for_testing(OracleEngine())
+    try:
+        mdl = _make_bimodal()
+        with E.use_rng(E.PhiloxRng(SEED)):
+            mdl.train_joint(BM_EPOCHS)
+        ref = _bimodal_state(mdl)
+    finally:
+        E.set_engine_for_testing(None)
+    a, b = np.load(tmp_path / "bimodal_rank0.npz"), np.load(tmp_path / "bimodal_rank1.npz")
+    for k in ref:
+        np.testing.assert_array_equal(a[k], b[k])                    # replicas and their reports stay identical
+    from golden_utils import rel_fro
+    for i in range(2):
+        for k, tol in ((f"W{i}", 5e-5), (f"hb{i}", 2e-4), (f"vb{i}", 2e-4), (f"Wm{i}", 2e-4)):
+            assert rel_fro(a[k], ref[k]) < tol, (k, rel_fro(a[k], ref[k]))
+    assert np.allclose(a["mse1"], ref["mse1"], rtol=1e-4) and np.allclose(a["mse2"], ref["mse2"], rtol=1e-4)
+    assert np.allclose(a["cd"], ref["cd"], rtol=1e-4)

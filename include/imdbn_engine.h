@@ -143,8 +143,19 @@ int    imdbn_device_info(int* cu_count, char* arch, size_t n);
 size_t imdbn_ws_bytes(int V, int H, int B);
 /* tuning knobs (split-K factors); 0 = automatic */
 int    imdbn_set_tuning(int ksplit_up, int ksplit_down);
-/* named tuning/testing knobs: "ksplit_up", "ksplit_down", "generic_k3" (1 = force the unaligned-shape K3) */
+/* named tuning/testing knobs (process-wide defaults): "ksplit_up", "ksplit_down", "generic_k3" (1 = force the unaligned-shape
+ * K3), "k1s_ks", "k2s_rows", "down_rows", "chain_rows", "no_k1s", "no_k2s", "no_bits", "no_prefetch", "no_chain_kernel", ...;
+ * none of them changes results beyond fp32 summation order, none is needed for normal use */
 int    imdbn_set_option(const char* name, int value);
+/* The same knobs per caller instead of per process: a handle starts as a copy of the process defaults, takes
+ * imdbn_options_set(name, value) (every name of imdbn_set_option but "dbg"), and imdbn_use_options(handle) binds it to the
+ * CALLING THREAD: engine calls made by that thread read the handle (NULL = back to the process defaults).  Knobs that shape
+ * the workspace layout (split-K factors, tile heights) must agree between calls that share a workspace. */
+typedef struct imdbn_options imdbn_options;
+imdbn_options* imdbn_options_create(void);
+void   imdbn_options_destroy(imdbn_options* o);
+int    imdbn_options_set(imdbn_options* o, const char* name, int value);
+int    imdbn_use_options(const imdbn_options* o);
 /* per-kernel timing of the update kernel with HIP events on the launch stream (bench.py roofline) */
 int    imdbn_profile_enable(int on);
 int    imdbn_profile_read(double* total_ms, int* launches);   /* synchronises the recorded events */

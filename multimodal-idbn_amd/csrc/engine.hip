@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <new>
 #include <vector>
 
 #include "../../include/imdbn_engine.h"
@@ -25,22 +26,48 @@ using namespace imdbn;
 namespace {
 
 thread_local char g_err[512] = "";
-int g_ks_up = 0, g_ks_down = 0;
-bool g_no_fast_k3 = false;
-bool g_no_fast_k1 = false;
-bool g_no_fused_up = false;
-int g_k4_rows = 0;          // tuning: batch rows per chain-kernel block (0 = automatic)
-int g_no_rank_loop = 0;     // testing: one update-kernel launch per gathered rank block
-int g_no_chain_kernel = 0;  // testing: run chains as one launch per half step
-int g_no_rank_acc = 0;   // testing: tile-wise rank loop (k3_body_ranks) even when the accumulating form applies
-int g_min_rank_loop = 2;  // apply_factors: rank blocks from which the single-launch rank loop is used (1 block: the plain update kernel, 46 vs 60 us)
-int g_no_prefetch = 0;   // testing: ignore imdbn_cd_opts.next_data
-int g_no_bits = 0;  // testing: never use the bit-packed hidden operand
-int g_down_tr = 0;  // tuning: rows per fused-K2 block (0 = automatic)
-int g_no_k1s = 0;  // testing: never use the LDS-DMA streaming K1 for binary operands (k1_stream)
-int g_k1s_ks = 0;  // tuning: K slices of k1_stream (0 = automatic)
-int g_no_k2s = 0;  // testing: never use k2_stream (the fused K2 for a bit-plane hidden operand, one tile per CU)
-int g_k2s_tr = 0;  // tuning: rows per k2_stream block (0 = automatic; multiple of 8, <= 48)
+// Tuning / testing knobs.  The process-wide defaults are set by imdbn_set_option / imdbn_set_tuning; a caller that wants its own
+// (two engines with different settings in one process) creates an imdbn_options handle and binds it to its thread with
+// imdbn_use_options: every engine call made by that thread then reads the handle instead of the defaults.  Knobs that shape the
+// workspace layout (split-K factors, tile heights) must be the same for all calls that share a workspace.
+struct Tuning {
+    int ks_up = 0, ks_down = 0;      // split-K factors of the generic propagation kernels (0 = automatic)
+    bool no_fast_k3 = false;         // testing: force the unaligned-shape update kernel
+    bool no_fast_k1 = false;
+    bool no_fused_up = false;
+    int k4_rows = 0;                 // tuning: batch rows per chain-kernel block (0 = automatic)
+    int no_rank_loop = 0;            // testing: one update-kernel launch per gathered rank block
+    int no_chain_kernel = 0;         // testing: run chains as one launch per half step
+    int no_rank_acc = 0;             // testing: tile-wise rank loop (k3_body_ranks) even when the accumulating form applies
+    int min_rank_loop = 2;           // apply_factors: rank blocks from which the single-launch rank loop is used (1 block: the plain update kernel, 46 vs 60 us)
+    int no_prefetch = 0;             // testing: ignore imdbn_cd_opts.next_data
+    int no_bits = 0;                 // testing: never use the bit-packed hidden operand
+    int down_tr = 0;                 // tuning: rows per fused-K2 block (0 = automatic)
+    int no_k1s = 0;                  // testing: never use the LDS-DMA streaming K1 for binary operands (k1_stream)
+    int k1s_ks = 0;                  // tuning: K slices of k1_stream (0 = automatic)
+    int no_k2s = 0;                  // testing: never use k2_stream (the fused K2 for a bit-plane hidden operand, one tile per CU)
+    int k2s_tr = 0;                  // tuning: rows per k2_stream block (0 = automatic; multiple of 8, <= 48)
+};
+Tuning g_defaults;
+thread_local const Tuning* t_bound = nullptr;
+inline const Tuning& tune() { return t_bound ? *t_bound : g_defaults; }
+#define g_ks_up (tune().ks_up)
+#define g_ks_down (tune().ks_down)
+#define g_no_fast_k3 (tune().no_fast_k3)
+#define g_no_fast_k1 (tune().no_fast_k1)
+#define g_no_fused_up (tune().no_fused_up)
+#define g_k4_rows (tune().k4_rows)
+#define g_no_rank_loop (tune().no_rank_loop)
+#define g_no_chain_kernel (tune().no_chain_kernel)
+#define g_no_rank_acc (tune().no_rank_acc)
+#define g_min_rank_loop (tune().min_rank_loop)
+#define g_no_prefetch (tune().no_prefetch)
+#define g_no_bits (tune().no_bits)
+#define g_down_tr (tune().down_tr)
+#define g_no_k1s (tune().no_k1s)
+#define g_k1s_ks (tune().k1s_ks)
+#define g_no_k2s (tune().no_k2s)
+#define g_k2s_tr (tune().k2s_tr)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
@@ -857,34 +884,46 @@ size_t imdbn_ws_bytes(int V, int H, int B) {
 }
 
 int imdbn_set_tuning(int ksplit_up, int ksplit_down) {
-    g_ks_up = std::max(0, ksplit_up);
-    g_ks_down = std::max(0, ksplit_down);
+    g_defaults.ks_up = std::max(0, ksplit_up);
+    g_defaults.ks_down = std::max(0, ksplit_down);
     return 0;
 }
 
-int imdbn_set_option(const char* name, int value) {
+static int set_opt(Tuning& t, const char* name, int value) {
     if (!name) return fail(IMDBN_E_INVALID, "null option name");
-    if (!strcmp(name, "ksplit_up")) g_ks_up = std::max(0, value);
-    else if (!strcmp(name, "ksplit_down")) g_ks_down = std::max(0, value);
-    else if (!strcmp(name, "generic_k3")) g_no_fast_k3 = value != 0;
-    else if (!strcmp(name, "down_rows")) { if (value != 0 && (value < 4 || value > 32 || value % 4)) return fail(IMDBN_E_INVALID, "down_rows must be 0 or a multiple of 4 in [4, 32]"); g_down_tr = value; }
-    else if (!strcmp(name, "no_rank_loop")) g_no_rank_loop = value;
-    else if (!strcmp(name, "no_chain_kernel")) g_no_chain_kernel = value;
-    else if (!strcmp(name, "chain_rows")) { if (value < 0 || value > 16) return fail(IMDBN_E_INVALID, "chain_rows must be in [0, 16]"); g_k4_rows = value; }
-    else if (!strcmp(name, "no_bits")) g_no_bits = value;
-    else if (!strcmp(name, "no_prefetch")) g_no_prefetch = value;
-    else if (!strcmp(name, "no_rank_acc")) g_no_rank_acc = value;
-    else if (!strcmp(name, "min_rank_loop")) g_min_rank_loop = value;
+    if (!strcmp(name, "ksplit_up")) t.ks_up = std::max(0, value);
+    else if (!strcmp(name, "ksplit_down")) t.ks_down = std::max(0, value);
+    else if (!strcmp(name, "generic_k3")) t.no_fast_k3 = value != 0;
+    else if (!strcmp(name, "down_rows")) { if (value != 0 && (value < 4 || value > 32 || value % 4)) return fail(IMDBN_E_INVALID, "down_rows must be 0 or a multiple of 4 in [4, 32]"); t.down_tr = value; }
+    else if (!strcmp(name, "no_rank_loop")) t.no_rank_loop = value;
+    else if (!strcmp(name, "no_chain_kernel")) t.no_chain_kernel = value;
+    else if (!strcmp(name, "chain_rows")) { if (value < 0 || value > 16) return fail(IMDBN_E_INVALID, "chain_rows must be in [0, 16]"); t.k4_rows = value; }
+    else if (!strcmp(name, "no_bits")) t.no_bits = value;
+    else if (!strcmp(name, "no_prefetch")) t.no_prefetch = value;
+    else if (!strcmp(name, "no_rank_acc")) t.no_rank_acc = value;
+    else if (!strcmp(name, "min_rank_loop")) t.min_rank_loop = value;
     else if (!strcmp(name, "dbg")) g_dbg = value;
-    else if (!strcmp(name, "no_k1s")) g_no_k1s = value;
-    else if (!strcmp(name, "k1s_ks")) g_k1s_ks = std::max(0, value);
-    else if (!strcmp(name, "no_k2s")) g_no_k2s = value;
-    else if (!strcmp(name, "k2s_rows")) { if (value != 0 && (value < 8 || value > 48 || value % 8)) return fail(IMDBN_E_INVALID, "k2s_rows must be 0 or a multiple of 8 in [8, 48]"); g_k2s_tr = value; }
-    else if (!strcmp(name, "generic_k1")) g_no_fast_k1 = value != 0;
-    else if (!strcmp(name, "no_fused_up")) g_no_fused_up = value != 0;
+    else if (!strcmp(name, "no_k1s")) t.no_k1s = value;
+    else if (!strcmp(name, "k1s_ks")) t.k1s_ks = std::max(0, value);
+    else if (!strcmp(name, "no_k2s")) t.no_k2s = value;
+    else if (!strcmp(name, "k2s_rows")) { if (value != 0 && (value < 8 || value > 48 || value % 8)) return fail(IMDBN_E_INVALID, "k2s_rows must be 0 or a multiple of 8 in [8, 48]"); t.k2s_tr = value; }
+    else if (!strcmp(name, "generic_k1")) t.no_fast_k1 = value != 0;
+    else if (!strcmp(name, "no_fused_up")) t.no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);
     return 0;
 }
+
+int imdbn_set_option(const char* name, int value) { return set_opt(g_defaults, name, value); }
+
+struct imdbn_options { Tuning t; };
+imdbn_options* imdbn_options_create(void) { return new (std::nothrow) imdbn_options{g_defaults}; }      // starts as a copy of the defaults
+void imdbn_options_destroy(imdbn_options* o) { if (o && t_bound == &o->t) t_bound = nullptr; delete o; }
+int imdbn_options_set(imdbn_options* o, const char* name, int value) {
+    if (!o) return fail(IMDBN_E_INVALID, "null options handle");
+    if (name && !strcmp(name, "dbg")) return fail(IMDBN_E_INVALID, "dbg is process-wide (imdbn_set_option)");
+    return set_opt(o->t, name, value);
+}
+int imdbn_use_options(const imdbn_options* o) { t_bound = o ? &o->t : nullptr; return 0; }
 
 int imdbn_profile_enable(int on) {
     if (on && g_prof.ev.empty()) {
@@ -1170,8 +1209,9 @@ static FactorWireArgs wire_layout(int V, int H, int B, int binary, size_t* compa
     w.f_vpos = (size_t)((const char*)L.vis_tr[0] - fb);
     w.f_vneg = (size_t)((const char*)L.vis_tr[1] - fb);
     w.f_cs_hpos = (size_t)((const char*)L.cs_hpos - fb);
-    w.f_flags = (size_t)((const char*)L.flags - fb); w.n_flags = (size_t)((const char*)L.hid_tr[0] - (const char*)L.flags);
-    w.f_cs_vpos = (size_t)((const char*)L.cs_vpos - fb); w.n_cs_vpos = (size_t)((const char*)L.cs_vneg - (const char*)L.cs_vpos);
+    // (exact sizes, both multiples of 16: the alignment padding behind them is copied from the block itself either way)
+    w.f_flags = (size_t)((const char*)L.flags - fb); w.n_flags = (size_t)L.P * cdiv(L.Vpad, 64) * 4;
+    w.f_cs_vpos = (size_t)((const char*)L.cs_vpos - fb); w.n_cs_vpos = (size_t)L.P * V * 4;
     w.head_bytes = w.f_vpos;                                            // flags .. loss_part precede the visible planes
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t bits = up((size_t)V * L.Bp / 8);

@@ -66,6 +66,23 @@ class HipEngine:
         N.check(self._lib.imdbn_set_option(name.encode(), int(value)), "imdbn_set_option")
         self._ws.clear(); self._pf.clear(); self._pf_ok.clear()
 
+    # per-caller knobs (imdbn_options): a handle bound to the calling thread overrides the process defaults
+    def options_create(self, **knobs):
+        h = C.c_void_p(self._lib.imdbn_options_create())
+        if not h:
+            raise N.EngineError("imdbn_options_create failed")
+        for k, v in knobs.items():
+            N.check(self._lib.imdbn_options_set(h, k.encode(), int(v)), "imdbn_options_set")
+        return h
+
+    def use_options(self, handle):
+        """Bind `handle` (None: the process defaults) to this thread; workspaces are re-derived (the layout may differ)."""
+        N.check(self._lib.imdbn_use_options(handle), "imdbn_use_options")
+        self._ws.clear(); self._pf.clear(); self._pf_ok.clear()
+
+    def options_destroy(self, handle):
+        self._lib.imdbn_options_destroy(handle)
+
     def profile(self, on: bool):
         N.check(self._lib.imdbn_profile_enable(1 if on else 0), "imdbn_profile_enable")
 

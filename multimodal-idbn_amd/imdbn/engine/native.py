@@ -66,6 +66,10 @@ SIGNATURES = {
     "imdbn_ws_bytes": (_SZ, [_INT, _INT, _INT]),
     "imdbn_set_tuning": (_INT, [_INT, _INT]),
     "imdbn_set_option": (_INT, [C.c_char_p, _INT]),
+    "imdbn_options_create": (_P, []),
+    "imdbn_options_destroy": (None, [_P]),
+    "imdbn_options_set": (_INT, [_P, C.c_char_p, _INT]),
+    "imdbn_use_options": (_INT, [_P]),
     "imdbn_profile_enable": (_INT, [_INT]),
     "imdbn_profile_read": (_INT, [C.POINTER(C.c_double), C.POINTER(_INT)]),
     "imdbn_debug_stamps": (_INT, [C.POINTER(C.c_longlong), _INT]),

@@ -41,6 +41,23 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(native.CdOpts) == 88            # 9 x 4 B + pad + next_data, ld_next, next_slot, data_slot, data_binary, next_binary, fwd_out, ld_fwd
 
 
+def test_options_handle_is_separate_from_the_process_defaults():
+    """imdbn_options: a per-caller copy of the knobs, bound to the calling thread with imdbn_use_options."""
+    import ctypes as C
+    lib = native.lib()
+    h = C.c_void_p(lib.imdbn_options_create())
+    assert h
+    assert lib.imdbn_options_set(h, b"no_k1s", 1) == 0 and lib.imdbn_options_set(h, b"k2s_rows", 24) == 0
+    assert lib.imdbn_options_set(h, b"k2s_rows", 23) != 0            # same validation as imdbn_set_option
+    assert lib.imdbn_options_set(h, b"no_such_knob", 1) != 0
+    assert lib.imdbn_options_set(h, b"dbg", 1) != 0                  # the debug stamps are process-wide
+    assert lib.imdbn_options_set(None, b"no_k1s", 1) != 0
+    assert lib.imdbn_use_options(h) == 0 and lib.imdbn_use_options(None) == 0
+    assert lib.imdbn_use_options(h) == 0
+    lib.imdbn_options_destroy(h)                                     # destroying the bound handle unbinds it
+    assert lib.imdbn_set_option(b"no_k1s", 0) == 0
+
+
 def test_no_gpu_call_reports_nodevice_as_exception():
     import torch
     import pytest

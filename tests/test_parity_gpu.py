@@ -797,6 +797,42 @@ def test_idbn_train_lookahead_with_a_ragged_last_batch_equals_plain_loop(tmp_pat
         os.chdir(cwd)
 
 
+def test_options_handle_overrides_the_defaults_for_the_bound_thread_only(_native):
+    """imdbn_options / imdbn_use_options: the knobs of a bound handle act like the same imdbn_set_option settings (bit for
+    bit), and unbinding restores the process defaults untouched."""
+    from imdbn import engine as E
+    V, H, B = 2048, 512, 64
+    g = np.random.default_rng(3)
+    Xs = [P.T((g.random((B, V), dtype=F32) > 0.8).astype(F32), DEV) for _ in range(2)]
+
+    def run():
+        r, _, _ = _mk(V, H, None, seed=4)
+        with E.use_rng(E.PhiloxRng(seed=3)):
+            ls = [float(r.train_epoch(x, 0, 1, CD=1)) for x in Xs]
+        return ls, [P.N(getattr(r, k)) for k in P.KEYS]
+
+    base = run()
+    h = _native.options_create(no_k1s=1, no_k2s=1)
+    try:
+        _native.use_options(h)
+        bound = run()
+        _native.use_options(None)
+        again = run()
+    finally:
+        _native.use_options(None)
+        _native.options_destroy(h)
+    _native.set_option("no_k1s", 1); _native.set_option("no_k2s", 1)
+    try:
+        glob = run()
+    finally:
+        _native.set_option("no_k1s", 0); _native.set_option("no_k2s", 0)
+    assert bound[0] == glob[0] and all(np.array_equal(a, b) for a, b in zip(bound[1], glob[1]))
+    assert again[0] == base[0] and all(np.array_equal(a, b) for a, b in zip(again[1], base[1]))
+    from golden_utils import rel_fro
+    assert rel_fro(bound[1][0], base[1][0]) < 1e-3          # a different kernel path: the same update up to summation order / a near-tie
+    assert any(not np.array_equal(a, b) for a, b in zip(bound[1], base[1])), "the bound knobs had no effect"
+
+
 @pytest.mark.parametrize("V,H,B", [(300, 128, 33), (2048, 512, 64), (777, 45, 100)])
 def test_assoc_update_alone_matches_oracle(V, H, B, _native):
     """imdbn_rbm_assoc_update (K3 on its own): the weight / bias update of rbm.py:209-224 from caller tensors."""

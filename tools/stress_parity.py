@@ -67,7 +67,8 @@ for case in range(n_cases):
         with E.use_rng(E.PhiloxRng(seed=seed)):
             d0, d1 = P.T(Xs[0], DEV), P.T(Xs[1], DEV)
             l0 = float(r.train_epoch(d0, 2, 10, CD=cd, next_data=d1))
-            l1 = float(r.train_epoch(d1, 2, 10, CD=cd))
+            l1, fw = r.train_epoch(d1, 2, 10, CD=cd, return_forward=True)      # update + forward as one engine call
+            l1, fw = float(l1), P.N(fw)
             Dz = groups[0][0] if groups else max(1, V // 3)
             vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
             vk[:, :Dz] = Xs[0][:, :Dz]; km[:, :Dz] = 1
@@ -77,10 +78,11 @@ for case in range(n_cases):
         s = PhiloxStream(seed)
         o0 = O.train_epoch(st, Xs[0], 2, cd, s)
         o1 = O.train_epoch(st, Xs[1], 2, cd, s)
+        of = O.forward(st, Xs[1])
         oo = O.conditional_gibbs(st, vk, km, s, n_steps=3)
         oc = O.train_epoch_clamped(st, vk, km, 2, s, CD=1, cond_init_steps=10, sample_h=False)
         errs = {"loss0": abs(l0 - o0) / max(abs(o0), 1e-6), "loss1": abs(l1 - o1) / max(abs(o1), 1e-6),
-                "chain": rel(out, oo, 1e-6), "lossc": abs(lc - oc) / max(abs(oc), 1e-4)}
+                "chain": rel(out, oo, 1e-6), "forward": rel(fw, of, 1e-6), "lossc": abs(lc - oc) / max(abs(oc), 1e-4)}
         for k in P.KEYS:
             errs[k] = rel(P.N(getattr(r, k)), getattr(st, k), 2e-6)
         if FAST:
@@ -119,10 +121,16 @@ for case in range(n_cases):
             Xg = g.random((R * Bl, V), dtype=F32)
             Xg = (Xg > 0.6).astype(F32) if binary else Xg
             seed = int(g.integers(1, 1 << 30))
-            wires = torch.stack([eng.pack_factors(r2, eng.cd_factors(r2, P.T(Xg[k * Bl:(k + 1) * Bl], DEV), cd, E.PhiloxRng(seed=seed, row0=k * Bl)), Bl, binary).clone()
-                                 for k in range(R)])
             lr_, mom_ = r2._lr_mom(2)
-            ld = float(eng.apply_factors_wire(r2, wires, eng.unpack_factors(r2, wires, Bl, binary, planes_only=True), Bl, R * Bl, lr_, mom_))
+            if case % 2 == 0:
+                wires = torch.stack([eng.pack_factors(r2, eng.cd_factors(r2, P.T(Xg[k * Bl:(k + 1) * Bl], DEV), cd, E.PhiloxRng(seed=seed, row0=k * Bl)), Bl, binary).clone()
+                                     for k in range(R)])
+                ld = float(eng.apply_factors_wire(r2, wires, eng.unpack_factors(r2, wires, Bl, binary, planes_only=True), Bl, R * Bl, lr_, mom_))
+            else:       # the fused halves (cd_factors_wire with the next rank's rows as the prefetch hint, apply_wire)
+                shards = [P.T(Xg[k * Bl:(k + 1) * Bl], DEV) for k in range(R)]
+                wires = torch.stack([eng.cd_factors_wire(r2, shards[k], cd, E.PhiloxRng(seed=seed, row0=k * Bl), binary,
+                                                         next_data=shards[k + 1] if k + 1 < R else None).clone() for k in range(R)])
+                ld = float(eng.apply_wire(r2, wires, Bl, R * Bl, binary, lr_, mom_))
             O.reset_margin()
             od = O.train_epoch(st2, Xg, 2, cd, PhiloxStream(seed))
             errs = {"dp loss": abs(ld - od) / max(abs(od), 1e-6)}

@@ -334,7 +334,7 @@ def main():
     # exchange in a process that has seen a GPU error, and no rank ever switches collectives on its own.
     if use_dp:
         E.dp.enable(force=args.force_dp, mode=args.dp_mode, binary_data=not args.dp_full_planes)   # the synthetic batches are 0/1 images
-    dt, t_enq, stamps, t0, (k3_ms, k3_n), loss = timed_region(world == 1 and not use_dp and not args.no_k3_events)
+    dt, t_enq, stamps, t0, (k3_ms, k3_n), loss = timed_region(not args.no_k3_events and (not use_dp or args.dp_mode == "factors"))
 
     def replicas_identical():
         if world == 1:
@@ -395,7 +395,11 @@ def main():
                 stale = pm.get("engine_source_sha") != _engine_source_sha()
             except Exception:
                 pass
-            out["roofline"] = {"kernel": "assoc_update (K3)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+            kname = "assoc_update (K3)"
+            if use_dp:       # the update from all ranks' factor blocks in one launch: the same 240 MB of weights move once
+                kname = f"assoc_update_planes_ranks (K3, {world} rank block{'s' if world > 1 else ''})" if world > 1 else "assoc_update (K3, data-parallel path)"
+                traffic, tsrc, stale = None, None, None
+            out["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                                "traffic_measured_on_other_sources": stale,
                                "avg_launch_us": 1e6 * avg_s, "launches": k3_n,

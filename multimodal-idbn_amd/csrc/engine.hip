@@ -1336,6 +1336,10 @@ static int apply_factors_impl(const imdbn_rbm_desc* d, const void* head, size_t 
     const int nh = cdiv(L.H, 128), nv = cdiv(L.V, 128);
     const int tpb = std::max(1, cdiv(nh * nv, std::max(cu_count(), 1)));
     const int brows = nh >= 2 ? 1 : 2;
+    // (bench.py roofline at N > 1: the update kernel bracketed with HIP events on its stream, every 4th call)
+    const bool prof = g_prof.on && (g_prof.calls++ % 4 == 0) && g_prof.used + 2 <= g_prof.ev.size();
+    if (prof) HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], c.s));
+    auto prof_end = [&]() -> int { if (prof) { HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], c.s)); g_prof.used += 2; } return 0; };
     // all rank blocks inside one launch (the weights move once) when the visible operands need <= 4 plane slices
     if (n_ranks >= g_min_rank_loop && !g_no_rank_loop && f.vneg_terms == 1) {
         f.vpos = (const bf16_t*)at_v(L.vis_tr[0], 0); f.vpos_flag = (const int*)at_h(L.flags, 0);
@@ -1349,7 +1353,7 @@ static int apply_factors_impl(const imdbn_rbm_desc* d, const void* head, size_t 
         else           { if (acc) hipLaunchKernelGGL((assoc_update_planes_ranks<1, true>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows);
                          else     hipLaunchKernelGGL((assoc_update_planes_ranks<1, false>), g, dim3(256), 0, c.s, f, rl, tpb, b, brows); }
         HIPCHK(hipGetLastError());
-        return 0;
+        return prof_end();
     }
     for (int rk = 0; rk < n_ranks; ++rk) {
         f.vpos = (const bf16_t*)at_v(L.vis_tr[0], rk); f.vpos_flag = (const int*)at_h(L.flags, rk);
@@ -1367,7 +1371,7 @@ static int apply_factors_impl(const imdbn_rbm_desc* d, const void* head, size_t 
 #undef LAUNCH_K3F
     }
     HIPCHK(hipGetLastError());
-    return 0;
+    return prof_end();
 }
 
 int imdbn_rbm_apply_factors(const imdbn_rbm_desc* d, const void* gathered, int n_ranks, size_t rank_stride, int rows_per_rank,

@@ -24,6 +24,9 @@ from imdbn import engine as _E
 def _row_pitch(h: int) -> int:
     """Row pitch in elements: H rounded up to 128 floats (512 B: the row segment one half-wave of the update kernel
     reads and writes) or else to 32 floats (128 B), whichever costs < 7 % extra memory."""
+    forced = int(os.environ.get("IMDBN_ROW_PITCH_ABS", "0"))       # layout experiments: an absolute pitch (>= h, multiple of 4)
+    if forced >= h and forced % 4 == 0:
+        return forced
     for q in (int(os.environ.get("IMDBN_ROW_PITCH", "128")), 32):
         p = (h + q - 1) // q * q
         if (p - h) * 16 <= h:

@@ -85,6 +85,10 @@ typedef struct imdbn_rng {
     int64_t  tape_used;     /* out */
     int64_t  cat_used;      /* out */
     uint64_t draws_used;    /* out: draw tensors consumed (advance `offset` by this) */
+    const uint64_t* dev_offset; /* PHILOX, nullable: a device-resident counter the kernels ADD to `offset` when they run.  A call
+                               sequence captured into a hipGraph bakes `offset` in; with dev_offset set and an
+                               imdbn_rng_advance(dev_offset, draws_used, stream) node behind it, every replay of the graph draws
+                               fresh numbers -- exactly those the same calls would draw issued one by one. */
 } imdbn_rng;
 
 /* One half-step pair v -> h -> v' of a conditional chain
@@ -165,6 +169,10 @@ int    imdbn_debug_stamps(long long* out, int n);
 /* test / tuning aid: byte offset of a named internal buffer inside the workspace of an (V, H, B) call ("vis_bits0/1", "hid_bits",
  * "vis_tr0/1", "hid_tr0/1", "cs_hpos/hneg/vpos/vneg", "flags", "partial", "vis_rm1"); the layout is NOT part of the ABI */
 int    imdbn_debug_ws_offset(int V, int H, int B, const char* name, size_t* offset);
+
+/* *dev_offset += n on `stream` (see imdbn_rng.dev_offset).  Every engine call is a plain sequence of kernel launches on the caller's
+ * stream -- no host synchronisation, no allocation, no memcpy -- so it can be recorded with hipStreamBeginCapture. */
+int imdbn_rng_advance(uint64_t* dev_offset, uint64_t n, imdbn_stream_t stream);
 
 /* ---- K1: p(h|v)   replaces RBM.forward (rbm.py:81-92) ---------------------------------- */
 /* out_prob[B][H] = sigmoid((v W + c)/T);  out_sample (nullable) = 1[out_prob > U] */

@@ -34,11 +34,16 @@ struct DrawSrc {
     uint64_t draw;       // Philox draw number
     int64_t row0;
     int N;               // row length of the logical tensor
+    const unsigned long long* base;   // nullable: a device-resident counter added to `draw` (imdbn_rng.dev_offset: a captured graph
+                                      // replays with fresh draws because a node of the graph advances the counter)
 };
+
+__device__ __forceinline__ uint64_t draw_no(const DrawSrc& s) { return s.draw + (s.base ? (uint64_t)*s.base : 0ull); }
 
 __device__ __forceinline__ uint4 draw_block(const DrawSrc& s, int b, int n) {
     const uint64_t row = (uint64_t)(s.row0 + b);
-    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)row, (uint32_t)s.draw, (uint32_t)(s.draw >> 32)),
+    const uint64_t dn = draw_no(s);
+    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)row, (uint32_t)dn, (uint32_t)(dn >> 32)),
                          make_uint2((uint32_t)s.seed, (uint32_t)(s.seed >> 32)));
 }
 
@@ -46,7 +51,8 @@ __device__ __forceinline__ uint4 draw_block(const DrawSrc& s, int b, int n) {
 // component = global row & 3).  A Philox-4x32-10 call is ~40 quarter-rate integer multiplies (~900 cycles per wave):
 // with one call per element it was 3.4 of the 3.9 us of the fused K2 epilogue (8 rows per thread -> 8 calls, now 2).
 __device__ __forceinline__ uint4 draw_block4(const DrawSrc& s, uint64_t grow, int n) {
-    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)(grow >> 2), (uint32_t)s.draw, (uint32_t)(s.draw >> 32)),
+    const uint64_t dn = draw_no(s);
+    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)(grow >> 2), (uint32_t)dn, (uint32_t)(dn >> 32)),
                          make_uint2((uint32_t)s.seed, (uint32_t)(s.seed >> 32)));
 }
 __device__ __forceinline__ float u24(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }   // 2^-24
@@ -93,7 +99,8 @@ __device__ __forceinline__ float normal_from(uint32_t a, uint32_t b) {
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 __device__ __forceinline__ uint4 draw_block2(const DrawSrc& s, uint64_t grow, int n) {
-    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)(grow >> 1), (uint32_t)s.draw, (uint32_t)(s.draw >> 32)),
+    const uint64_t dn = draw_no(s);
+    return philox4x32_10(make_uint4((uint32_t)n, (uint32_t)(grow >> 1), (uint32_t)dn, (uint32_t)(dn >> 32)),
                          make_uint2((uint32_t)s.seed, (uint32_t)(s.seed >> 32)));
 }
 __device__ __forceinline__ float draw_normal(const DrawSrc& s, int b, int n) {

@@ -257,7 +257,7 @@ struct Rng {
         DrawSrc s{};
         s.N = N;
         if (!r) { bad = true; return s; }
-        s.seed = r->seed; s.row0 = r->row0; s.draw = r->offset + draws;
+        s.seed = r->seed; s.row0 = r->row0; s.draw = r->offset + draws; s.base = (const unsigned long long*)r->dev_offset;
         if (r->mode == IMDBN_RNG_REPLAY) {
             if (!r->tape || tpos + (int64_t)B * N > r->tape_len) { bad = true; return s; }
             s.tape = r->tape + tpos;
@@ -274,7 +274,7 @@ struct Rng {
         s.N = 1;
         if (n_groups == 0) { *uni = s; return; }
         if (!r) { bad = true; *uni = s; return; }
-        s.seed = r->seed; s.row0 = r->row0; s.draw = r->offset + draws;
+        s.seed = r->seed; s.row0 = r->row0; s.draw = r->offset + draws; s.base = (const unsigned long long*)r->dev_offset;
         if (r->mode == IMDBN_RNG_REPLAY) {
             if (!r->cat_tape || cpos + (int64_t)B * n_groups > r->cat_len) { bad = true; *uni = s; return; }
             *tape = r->cat_tape + cpos;
@@ -781,6 +781,7 @@ int run_chain_k4(Ctx& c, const float* vk, const float* mask, int64_t ldk, int n_
     a.state = out; a.lds = ldo;
     a.recs = L.chain_recs; a.n_steps = n_steps;
     a.seed = c.rng.r ? c.rng.r->seed : 0; a.row0 = c.rng.r ? c.rng.r->row0 : 0;
+    a.draw_base = c.rng.r ? (const unsigned long long*)c.rng.r->dev_offset : nullptr;
     a.mu = mu; a.ldmu = ldmu; a.Dz = Dz;
     a.vk = vk; a.mask = mask; a.ldk = ldk;
     // rows per block: enough blocks to spread the per-element work (Philox, Box-Muller, sigmoid) over the CUs;
@@ -973,6 +974,15 @@ int imdbn_profile_read(double* total_ms, int* launches) {
     if (total_ms) *total_ms = tot;
     if (launches) *launches = (int)(g_prof.used / 2);
     g_prof.used = 0;
+    return 0;
+}
+
+// the device-resident draw counter of imdbn_rng.dev_offset: += n, as a node of the caller's stream (or captured graph)
+__global__ void rng_advance_kernel(unsigned long long* p, unsigned long long n) { *p += n; }
+int imdbn_rng_advance(uint64_t* dev_offset, uint64_t n, imdbn_stream_t stream) {
+    if (!dev_offset) return fail(IMDBN_E_INVALID, "rng_advance: null counter");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, S(stream), (unsigned long long*)dev_offset, (unsigned long long)n);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -105,7 +105,7 @@ struct K4Args {
     float* state; int64_t lds;                     // fp32 visible state [B][V]: v0 in, final v out
     int rows;                                      // batch rows per block (<= 16): fewer rows = more CUs share the element-wise work
     const ChainRec* recs; int n_steps;
-    uint64_t seed; int64_t row0;
+    uint64_t seed; int64_t row0; const unsigned long long* draw_base;
     const float* mu; int64_t ldmu; int Dz;
     const float* vk; const float* mask; int64_t ldk;
     int dbg;                                       // 1: per-block stamps of chain step 2 (tools/stamps_probe.py)
@@ -113,7 +113,7 @@ struct K4Args {
 
 __device__ __forceinline__ DrawSrc k4_src(const K4Args& a, const ChainDraw& d, int N) {
     DrawSrc s;
-    s.tape = d.tape; s.seed = a.seed; s.draw = d.draw; s.row0 = a.row0; s.N = N;
+    s.tape = d.tape; s.seed = a.seed; s.draw = d.draw; s.row0 = a.row0; s.N = N; s.base = a.draw_base;
     return s;
 }
 

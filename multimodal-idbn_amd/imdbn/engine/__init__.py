@@ -14,6 +14,13 @@ from . import dp  # noqa: F401
 from .native import EngineError
 from .rng import PhiloxRng, ReplayRng
 
+
+def __getattr__(name):          # imdbn.engine.graph / CapturedSteps on demand (imports torch.cuda pieces)
+    if name == "CapturedSteps":
+        from .graph import CapturedSteps
+        return CapturedSteps
+    raise AttributeError(name)
+
 _hip = None
 _override = None
 _rng = None

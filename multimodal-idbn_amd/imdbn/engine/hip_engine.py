@@ -83,6 +83,11 @@ class HipEngine:
     def options_destroy(self, handle):
         self._lib.imdbn_options_destroy(handle)
 
+    def rng_advance(self, counter: torch.Tensor, n: int):
+        """counter[0] += n on the current stream (a node of the graph being captured)."""
+        assert counter.dtype == torch.int64 and counter.numel() == 1 and counter.is_cuda
+        N.check(self._lib.imdbn_rng_advance(_ptr(counter), int(n), self._stream(counter.device)), "imdbn_rng_advance")
+
     def profile(self, on: bool):
         N.check(self._lib.imdbn_profile_enable(1 if on else 0), "imdbn_profile_enable")
 
@@ -102,8 +107,8 @@ class HipEngine:
         # one workspace per (device, shape, STREAM): two same-shape RBMs driven from two streams must not share scratch
         key = (dev, V, H, B, torch.cuda.current_stream(dev).cuda_stream if torch.device(dev).type == "cuda" else 0)
         ws = self._ws.get(key)
-        need = int(self._lib.imdbn_ws_bytes(V, H, B))
-        if ws is None or ws.numel() < need:
+        if ws is None:
+            need = int(self._lib.imdbn_ws_bytes(V, H, B))
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
             self._ws[key] = ws
         return ws
@@ -113,6 +118,35 @@ class HipEngine:
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def _desc(self, rbm, need_momentum: bool) -> N.RbmDesc:
+        """The native descriptor of `rbm`.  Built (and validated) once per state of the parameter tensors: callers may re-bind
+        or move W / biases / momentum buffers at any time (SURVEY b-1), so the cached descriptor is keyed on their addresses."""
+        p = rbm._parameters
+        Wp, hbp, vbp = p.get("W"), p.get("hid_bias"), p.get("vis_bias")
+        dct = rbm.__dict__
+        if Wp is not None and hbp is not None and vbp is not None:
+            Wm, hbm, vbm = dct.get("W_m"), dct.get("hb_m"), dct.get("vb_m")
+            g = dct.get("softmax_groups")
+            key = (Wp.data_ptr(), Wp.stride(0), Wp.shape, hbp.data_ptr(), vbp.data_ptr(),
+                   Wm.data_ptr() if isinstance(Wm, torch.Tensor) else 0, hbm.data_ptr() if isinstance(hbm, torch.Tensor) else 0,
+                   vbm.data_ptr() if isinstance(vbm, torch.Tensor) else 0, Wm.stride(0) if isinstance(Wm, torch.Tensor) and Wm.dim() == 2 else 0,
+                   tuple(map(tuple, g)) if g else (), self.mode, bool(need_momentum))
+            cache = dct.get("_imdbn_desc")
+            hit = cache.get(bool(need_momentum)) if cache is not None else None
+            if hit is not None and hit[0] == key:
+                return hit[1]
+        d = self._build_desc(rbm, need_momentum)
+        if Wp is not None and hbp is not None and vbp is not None:
+            # (re-homing may have replaced the momentum buffers: key on what is there now)
+            Wm, hbm, vbm = dct.get("W_m"), dct.get("hb_m"), dct.get("vb_m")
+            g = dct.get("softmax_groups")
+            key = (Wp.data_ptr(), Wp.stride(0), Wp.shape, hbp.data_ptr(), vbp.data_ptr(),
+                   Wm.data_ptr() if isinstance(Wm, torch.Tensor) else 0, hbm.data_ptr() if isinstance(hbm, torch.Tensor) else 0,
+                   vbm.data_ptr() if isinstance(vbm, torch.Tensor) else 0, Wm.stride(0) if isinstance(Wm, torch.Tensor) and Wm.dim() == 2 else 0,
+                   tuple(map(tuple, g)) if g else (), self.mode, bool(need_momentum))
+            dct.setdefault("_imdbn_desc", {})[bool(need_momentum)] = (key, d)
+        return d
+
+    def _build_desc(self, rbm, need_momentum: bool) -> N.RbmDesc:
         W = rbm.W.data
         if not W.is_cuda:
             raise N.EngineError("HipEngine needs CUDA/HIP tensors (RBM.W is on %s)" % W.device)
@@ -169,6 +203,8 @@ class HipEngine:
         elif isinstance(rng, R.PhiloxRng):
             r.mode = N.RNG_PHILOX
             r.seed, r.offset, r.row0 = rng.seed, rng.offset, rng.row0
+            if rng.device_counter is not None:          # a capture is being recorded: draw number = offset + *counter at run time
+                r.dev_offset = rng.device_counter.data_ptr()
         else:
             raise N.EngineError("rng must be PhiloxRng or ReplayRng")
         return r, keep
@@ -292,8 +328,8 @@ class HipEngine:
         tag = getattr(x, "_imdbn_binary", None)
         if tag is not None:
             return bool(tag)
-        if self.binary_check == "never":
-            return False
+        if self.binary_check == "never" or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return False            # (a capture cannot synchronise: tag the static input tensor instead)
         key = id(x)
         hit = self._bin.get(key)
         if hit is not None and hit[0]() is x and hit[1] == (x.data_ptr(), x._version, tuple(x.shape)):

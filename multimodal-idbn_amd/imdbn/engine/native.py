@@ -35,6 +35,7 @@ class Rng(C.Structure):
         ("tape", C.c_void_p), ("tape_len", C.c_int64),
         ("cat_tape", C.c_void_p), ("cat_len", C.c_int64),
         ("tape_used", C.c_int64), ("cat_used", C.c_int64), ("draws_used", C.c_uint64),
+        ("dev_offset", C.c_void_p),
     ]
 
 
@@ -74,6 +75,7 @@ SIGNATURES = {
     "imdbn_profile_read": (_INT, [C.POINTER(C.c_double), C.POINTER(_INT)]),
     "imdbn_debug_stamps": (_INT, [C.POINTER(C.c_longlong), _INT]),
     "imdbn_debug_ws_offset": (_INT, [_INT, _INT, _INT, C.c_char_p, C.POINTER(_SZ)]),
+    "imdbn_rng_advance": (_INT, [_P, C.c_uint64, _P]),
     "imdbn_rbm_prop_up": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _F, C.POINTER(Rng), _P, _I64, _P, _I64, _P, _SZ, _P]),
     "imdbn_rbm_forward": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _INT, _P, _I64, _P, _SZ, _P]),
     "imdbn_rbm_free_energy": (_INT, [C.POINTER(RbmDesc), _P, _I64, _INT, _P, _P, _SZ, _P]),

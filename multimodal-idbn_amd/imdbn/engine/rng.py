@@ -27,6 +27,9 @@ class PhiloxRng:
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0          # number of draw tensors consumed so far
         self.row0 = int(row0)    # global index of local row 0 (data-parallel shard offset)
+        # graph capture (imdbn.engine.graph.CapturedSteps): a 1-element int64 device tensor the kernels add to `offset`
+        # when they RUN; set only while a capture is being recorded
+        self.device_counter = None
 
     def advance(self, n_draws: int):
         self.offset += int(n_draws)

@@ -88,6 +88,7 @@ class RBM(nn.Module):
         must not carry that storage: they are written as contiguous ``[V, H]`` tensors (stride ``(H, 1)``), exactly what
         the reference class -- or this one -- expects to unpickle."""
         state = self.__dict__.copy()
+        state.pop("_imdbn_desc", None)                 # the engine's cached native descriptor (raw addresses): never part of the state
         params = state["_parameters"].copy()
         W = params.get("W")
         if W is not None and not W.is_contiguous():

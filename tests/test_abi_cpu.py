@@ -36,7 +36,7 @@ def test_version_and_sizes():
 def test_struct_sizes_match_header_layout():
     import ctypes as C
     assert C.sizeof(native.RbmDesc) == 8 * 7 + 4 * 4 + 4 * 8
-    assert C.sizeof(native.Rng) == 8 + 8 * 3 + 8 * 4 + 8 * 3
+    assert C.sizeof(native.Rng) == 8 + 8 * 3 + 8 * 4 + 8 * 3 + 8
     assert C.sizeof(native.ChainStep) == 24
     assert C.sizeof(native.CdOpts) == 88            # 9 x 4 B + pad + next_data, ld_next, next_slot, data_slot, data_binary, next_binary, fwd_out, ld_fwd
 

@@ -133,6 +133,9 @@ __device__ __forceinline__ void k4_put(bf16_t* act, int AK, int row, int col, fl
 // rows 4*(l>>4)+r) at the end of each tile.
 // NW / NA are compile-time: a run-time `if (tw < nw)` puts a branch around every load and MFMA and the compiler then
 // waits vmcnt(0) before each MFMA (no overlap at all).
+#ifndef K4_SKIP_LOLO
+#define K4_SKIP_LOLO 0      // 1 was measured in round 2: GEMM phases 7.44 -> 7.28 us only (the phase is bound by the bytes in flight from L2, not by MFMA)
+#endif
 constexpr int K4_RING = 6;           // 12 was tried in round 2: the ring then spills (96 B/lane) and the GEMM phases go 7.5 -> 8.7 us
 template <int NW, int NA>
 __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB, const bf16_t* act, int AK,
@@ -167,8 +170,10 @@ __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB
             for (int ta = 0; ta < NA; ++ta) {
                 const uint4 af = *reinterpret_cast<const uint4*>(act + (ta * K4_ROWS + (l & 15)) * AK + 32 * min(kb, KB - 1) + 8 * (l >> 4));
 #pragma unroll
-                for (int tw = 0; tw < NW; ++tw)
+                for (int tw = 0; tw < NW; ++tw) {
+                    if (K4_SKIP_LOLO && ta == 1 && tw == 1) continue;     // lo x lo: 2^-22 of the product, below the hi/lo split's own error
                     acc[tw] = k4_mfma<NW>(af, ring[d][tw], acc[tw]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             load(ring[d], it0 + d + K4_RING);

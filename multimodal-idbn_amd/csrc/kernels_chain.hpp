@@ -134,9 +134,9 @@ __device__ __forceinline__ void k4_put(bf16_t* act, int AK, int row, int col, fl
 // NW / NA are compile-time: a run-time `if (tw < nw)` puts a branch around every load and MFMA and the compiler then
 // waits vmcnt(0) before each MFMA (no overlap at all).
 #ifndef K4_SKIP_LOLO
-#define K4_SKIP_LOLO 0      // 1 was measured in round 2: GEMM phases 7.44 -> 7.28 us only (the phase is bound by the bytes in flight from L2, not by MFMA)
+#define K4_SKIP_LOLO 0      // 1 was measured in round 2: GEMM phases 7.44 -> 7.28 us only (not MFMA bound)
 #endif
-constexpr int K4_RING = 6;           // 12 was tried in round 2: the ring then spills (96 B/lane) and the GEMM phases go 7.5 -> 8.7 us
+constexpr int K4_RING = 6;           // round 2: 9 (242 VGPRs, no spill) -> GEMM phases 7.8 / 8.4 us, 12 (spills) -> 8.7 us, against 7.4 / 7.8 with 6: not bound by the bytes in flight
 template <int NW, int NA>
 __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB, const bf16_t* act, int AK,
                                         float* stage, int SP) {

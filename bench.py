@@ -210,7 +210,9 @@ def _spawn_ranks(n: int, argv) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *argv]
     print("[bench] starting ranks:", " ".join(cmd), file=sys.stderr, flush=True)
-    return subprocess.call(cmd)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # this pool's driver only has dmabuf IPC (RCCL needs it across processes)
+    return subprocess.call(cmd, env=env)
 
 
 def _under_profiler() -> bool:
@@ -238,6 +240,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank flow on one GPU)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (before anything initialises the GPU; see _spawn_ranks)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -41,6 +41,9 @@ def test_captured_train_epoch_replays_equal_eager_calls(V, H, B, binary):
     g = np.random.default_rng(V)
     mk = (lambda: (g.random((B, V), dtype=F32) > 0.7).astype(F32)) if binary else (lambda: g.random((B, V), dtype=F32))
     Xs = [P.T(mk(), DEV) for _ in range(7)]
+    for x in Xs:
+        x._imdbn_binary = binary        # both runs must take the same kernel path (an untagged tensor is checked -- or, after 64 unknown
+                                        # tensors in a row, no longer asked about and sent down the general path)
     ra, rb = _rbm(V, H, 3), _rbm(V, H, 3)
     with E.use_rng(E.PhiloxRng(seed=12)):
         la = [float(ra.train_epoch(x, 2, 10, CD=1)) for x in Xs]
@@ -67,6 +70,8 @@ def test_captured_layer_loop_and_clamped_update_equal_eager_calls():
     B = 32
     g = np.random.default_rng(5)
     Xs = [P.T((g.random((B, 400), dtype=F32) > 0.8).astype(F32), DEV) for _ in range(5)]
+    for x in Xs:
+        x._imdbn_binary = True
     Ys = [P.T(np.eye(8, dtype=F32)[g.integers(0, 8, B)], DEV) for _ in range(5)]
 
     def build():

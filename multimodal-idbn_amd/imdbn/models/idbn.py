@@ -15,7 +15,7 @@ from typing import List, Optional
 import torch
 
 from imdbn.models.rbm import RBM
-from imdbn.utils import batches
+from imdbn.utils import batches, rows_on_device
 
 
 class iDBN:
@@ -105,7 +105,7 @@ class iDBN:
             losses = []
             # one batch of lookahead: the first layer prepares the operand forms of the following batch during its
             # weight update (RBM.train_epoch next_data=); the batches and their order are unchanged
-            dev_batch = lambda item: None if item is None else item[0].to(self.device).view(item[0].size(0), -1).float()
+            dev_batch = lambda item: None if item is None else rows_on_device(item[0], self.device)
             it = iter(batches(self.dataloader))
             cur = dev_batch(next(it, None))
             while cur is not None:
@@ -130,7 +130,7 @@ class iDBN:
     @torch.no_grad()
     def represent(self, x: torch.Tensor, upto_layer: Optional[int] = None) -> torch.Tensor:
         """idbn.py:319-323."""
-        v = x.view(x.size(0), -1).float().to(self.device)
+        v = rows_on_device(x, self.device)
         L = len(self.layers) if (upto_layer is None) else max(0, min(len(self.layers), int(upto_layer)))
         for i in range(L):
             v = self.layers[i].forward(v)
@@ -139,7 +139,7 @@ class iDBN:
     @torch.no_grad()
     def reconstruct(self, x: torch.Tensor) -> torch.Tensor:
         """idbn.py:336-344."""
-        cur = x.view(x.size(0), -1).float().to(self.device)
+        cur = rows_on_device(x, self.device)
         for rbm in self.layers:
             cur = rbm.forward(cur)
         for rbm in reversed(self.layers):

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from imdbn import engine as _E
 from imdbn.models.idbn import iDBN
 from imdbn.models.rbm import RBM
-from imdbn.utils import batches
+from imdbn.utils import batches, rows_on_device
 
 WARMUP_Y_EPOCHS = 8          # imdbn.py:540
 Z_CLAMP_EVERY = 50           # imdbn.py:600
@@ -124,7 +124,7 @@ class iMDBN(nn.Module):
         for b, (imgs, lbls) in enumerate(batches(self.dataloader)):
             if b >= n_batches:
                 break
-            z = self.image_idbn.represent(imgs.to(self.device).view(imgs.size(0), -1).float())
+            z = self.image_idbn.represent(rows_on_device(imgs, self.device))
             sum_z = z.sum(0) if sum_z is None else (sum_z + z.sum(0))
             n += z.size(0)
             class_counts += lbls.to(self.device).float().sum(0)
@@ -209,7 +209,7 @@ class iMDBN(nn.Module):
         for ep in range(int(epochs)):
             losses = []
             for img, _ in batches(self.dataloader):
-                v = img.to(self.device).view(img.size(0), -1).float()
+                v = rows_on_device(img, self.device)
                 for rbm in self.image_idbn.layers[:-1]:
                     v = rbm.forward(v)
                 losses.append(last.train_epoch(v, ep, epochs, CD=use_cd))
@@ -285,7 +285,7 @@ class iMDBN(nn.Module):
     def represent(self, batch: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
         """imdbn.py:501-506."""
         img_data, lbl_data = batch
-        img = img_data.to(self.device).view(img_data.size(0), -1).float()
+        img = rows_on_device(img_data, self.device)
         y = lbl_data.to(self.device).float()
         return self.joint_rbm.forward(torch.cat([self.image_idbn.represent(img), y], dim=1))
 
@@ -314,7 +314,7 @@ class iMDBN(nn.Module):
             acc = torch.zeros(5, device=self.device, dtype=torch.float64)   # n, top1, top3, ce_sum, mse_sum
             npix = None
             for b_idx, (img, y) in enumerate(batches(self.dataloader)):
-                img = img.to(self.device).view(img.size(0), -1).float()
+                img = rows_on_device(img, self.device)
                 y = y.to(self.device).float()
                 with torch.no_grad():
                     z_img = self.image_idbn.represent(img)

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from imdbn import engine as _E
 from imdbn.models.idbn import iDBN
 from imdbn.models.rbm import RBM
-from imdbn.utils import batches
+from imdbn.utils import batches, rows_on_device
 
 WARMUP_EPOCHS = 8            # imdbn_bimodal.py:736
 AUX_CD = 3                   # :762,:775,:800,:814  (clamped updates run CD-3 with sampled hidden units)
@@ -142,8 +142,8 @@ class iMDBN_BiModal(nn.Module):
         for b, (mod1, mod2) in enumerate(batches(self.dataloader)):
             if b >= n_batches:
                 break
-            z1 = self.mod1_dbn.represent(mod1.to(self.device).view(mod1.size(0), -1).float())
-            z2 = self.mod2_dbn.represent(mod2.to(self.device).view(mod2.size(0), -1).float())
+            z1 = self.mod1_dbn.represent(rows_on_device(mod1, self.device))
+            z2 = self.mod2_dbn.represent(rows_on_device(mod2, self.device))
             sum_z1 = z1.sum(0) if sum_z1 is None else (sum_z1 + z1.sum(0))
             sum_z2 = z2.sum(0) if sum_z2 is None else (sum_z2 + z2.sum(0))
             n += z1.size(0)
@@ -189,8 +189,8 @@ class iMDBN_BiModal(nn.Module):
     @torch.no_grad()
     def represent(self, batch: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
         mod1, mod2 = batch
-        z1 = self.mod1_dbn.represent(mod1.to(self.device).view(mod1.size(0), -1).float())
-        z2 = self.mod2_dbn.represent(mod2.to(self.device).view(mod2.size(0), -1).float())
+        z1 = self.mod1_dbn.represent(rows_on_device(mod1, self.device))
+        z2 = self.mod2_dbn.represent(rows_on_device(mod2, self.device))
         h = torch.cat([z1, z2], dim=1)
         for rbm in self.joint_layers:
             h = rbm.forward(h)
@@ -213,8 +213,8 @@ class iMDBN_BiModal(nn.Module):
             cd_losses = []
             acc = torch.zeros(3, device=self.device, dtype=torch.float64)      # n, mse_mod1_sum, mse_mod2_sum
             for mod1, mod2 in batches(self.dataloader):
-                v1 = mod1.to(self.device).view(mod1.size(0), -1).float()
-                v2 = mod2.to(self.device).view(mod2.size(0), -1).float()
+                v1 = rows_on_device(mod1, self.device)
+                v2 = rows_on_device(mod2, self.device)
                 B = v1.size(0)
                 with torch.no_grad():
                     z1 = self.mod1_dbn.represent(v1)

@@ -23,6 +23,37 @@ def _sliceable(dl) -> bool:
             and getattr(dl.batch_sampler, "sampler", None) is dl.sampler and not dl.pin_memory)
 
 
+_BIN_ALL: dict = {}       # id(dataset tensor) -> (weakref, (data_ptr, version), every element is exactly 0 or 1)
+
+
+def _all_binary(t: torch.Tensor):
+    """Is every element of the (whole, in-memory) dataset tensor exactly 0 or 1?  Asked once per tensor state; None for
+    non-float tensors.  The engine reads 0/1 batches as bit planes (HipEngine.data_is_binary)."""
+    import weakref
+    if not t.is_floating_point() or t.numel() == 0:
+        return None
+    hit = _BIN_ALL.get(id(t))
+    state = (t.data_ptr(), t._version)
+    if hit is not None and hit[0]() is t and hit[1] == state:
+        return hit[2]
+    val = bool(((t == 0) | (t == 1)).all())
+    if len(_BIN_ALL) > 64:
+        for k in [k for k, v in _BIN_ALL.items() if v[0]() is None]:
+            del _BIN_ALL[k]
+    _BIN_ALL[id(t)] = (weakref.ref(t), state, val)
+    return val
+
+
+def rows_on_device(t: torch.Tensor, device) -> torch.Tensor:
+    """``t.to(device).view(B, -1).float()`` -- what the training loops do with a batch -- keeping the "this batch is 0/1" tag
+    (``_imdbn_binary``: set by ``imdbn.datasets.DeviceLoader`` and by :func:`batches`) that a new view would drop."""
+    x = t.to(device).view(t.size(0), -1).float()
+    tag = getattr(t, "_imdbn_binary", None)
+    if tag is not None and x is not t:
+        x._imdbn_binary = bool(tag)
+    return x
+
+
 def batches(dl: Iterable) -> Iterator[Tuple[torch.Tensor, ...]]:
     """Yield the batches of `dl`; row slices of the underlying tensors when `dl` is a plain sequential DataLoader
     over a TensorDataset (identical contents and order), else `iter(dl)`."""
@@ -30,8 +61,15 @@ def batches(dl: Iterable) -> Iterator[Tuple[torch.Tensor, ...]]:
         yield from dl
         return
     tensors = dl.dataset.tensors
+    flags = [_all_binary(t) for t in tensors]          # one pass over the in-memory dataset, once: every slice of a 0/1 tensor is 0/1
     n, bs = len(dl.dataset), int(dl.batch_size)
     stop = (n // bs) * bs if dl.drop_last else n
     for s in range(0, stop, bs):
         e = min(s + bs, stop)
-        yield tuple(t[s:e] for t in tensors)
+        out = []
+        for t, f in zip(tensors, flags):
+            b = t[s:e]
+            if f is not None:
+                b._imdbn_binary = f
+            out.append(b)
+        yield tuple(out)

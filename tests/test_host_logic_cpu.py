@@ -83,3 +83,24 @@ def test_product_refuses_cpu_without_engine():
     r = RBM(8, 4, 0.1, 1e-4, 0.5).to("cpu")
     with pytest.raises(E.EngineError):
         r.forward(torch.zeros(2, 8))
+
+
+def test_batches_tag_binary_datasets_and_the_tag_survives_the_flatten():
+    """imdbn.utils.batches: a sequential DataLoader over an in-memory TensorDataset is asked ONCE whether its tensors are 0/1 and
+    every batch carries the answer; rows_on_device (the loops' `.to(device).view(B, -1).float()`) keeps it on the new view."""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from imdbn.utils import batches, rows_on_device
+    X = (torch.rand(10, 2, 6) > 0.5).float()
+    Y = torch.rand(10, 3)
+    got = list(batches(DataLoader(TensorDataset(X, Y), batch_size=4)))
+    assert [tuple(b[0].shape) for b in got] == [(4, 2, 6), (4, 2, 6), (2, 2, 6)]
+    assert all(b[0]._imdbn_binary is True and b[1]._imdbn_binary is False for b in got)
+    flat = rows_on_device(got[0][0], torch.device("cpu"))
+    assert flat.shape == (4, 12) and flat._imdbn_binary is True
+    X[0, 0, 0] = 0.5                                   # in-place change: the dataset is asked again
+    got = list(batches(DataLoader(TensorDataset(X, Y), batch_size=4)))
+    assert got[0][0]._imdbn_binary is False
+    shuffled = DataLoader(TensorDataset(X, Y), batch_size=4, shuffle=True)      # anything else goes through the DataLoader untouched
+    assert not hasattr(next(iter(batches(shuffled)))[0], "_imdbn_binary")
+    assert not hasattr(rows_on_device(torch.rand(3, 4), torch.device("cpu")), "_imdbn_binary")

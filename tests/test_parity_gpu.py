@@ -788,6 +788,7 @@ def test_idbn_train_lookahead_with_a_ragged_last_batch_equals_plain_loop(tmp_pat
             for epoch in range(2):
                 for s in range(0, 164, 64):
                     v = X[s:s + 64]
+                    v._imdbn_binary = True          # (what iDBN.train learns about the dataset tensor once: same kernel path in both runs)
                     for rbm in b.layers:
                         rbm.train_epoch(v, epoch, 2, CD=1)
                         v = rbm.forward(v)

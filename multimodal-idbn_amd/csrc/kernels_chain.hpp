@@ -133,6 +133,9 @@ __device__ __forceinline__ void k4_put(bf16_t* act, int AK, int row, int col, fl
 // rows 4*(l>>4)+r) at the end of each tile.
 // NW / NA are compile-time: a run-time `if (tw < nw)` puts a branch around every load and MFMA and the compiler then
 // waits vmcnt(0) before each MFMA (no overlap at all).
+#ifndef K4_NT_LOADS
+#define K4_NT_LOADS 0        // 1 (non-temporal fragment loads) measured in round 2: GEMM phases 7.6 / 8.0 us against 7.4 / 7.8
+#endif
 #ifndef K4_SKIP_LOLO
 #define K4_SKIP_LOLO 0      // 1 was measured in round 2: GEMM phases 7.44 -> 7.28 us only (not MFMA bound)
 #endif
@@ -150,7 +153,12 @@ __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB
         const int nt = w + K4_WAVES * (itc / KB), kb = itc - (itc / KB) * KB;
 #pragma unroll
         for (int tw = 0; tw < NW; ++tw)
-            b[tw] = *reinterpret_cast<const uint4*>(pl + tw * a.plane_stride + ((int64_t)(nt * KB + kb) * 64 + l) * 8);
+            {
+                typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+                const u32x4* q = reinterpret_cast<const u32x4*>(pl + tw * a.plane_stride + ((int64_t)(nt * KB + kb) * 64 + l) * 8);
+                const u32x4 x = K4_NT_LOADS ? __builtin_nontemporal_load(q) : *q;
+                b[tw] = make_uint4(x.x, x.y, x.z, x.w);
+            }
     };
     if (n_items == 0) return;
 #pragma unroll

@@ -20,6 +20,11 @@
 #pragma once
 #include "kernels_ew.hpp"
 
+#ifndef K4_NO_MFMA
+#define K4_NO_MFMA 0         // 1: timing experiment (round 2): without any matrix work the GEMM phases still take 6.8 - 7.0 us (7.4 - 7.8 with it):
+                              // the 544 KB of fragments reach a CU at ~80 GB/s (33 B/clk) whatever the ring depth or cache policy
+#endif
+
 namespace imdbn {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -44,6 +49,9 @@ __device__ __forceinline__ void k4_terms(float x, uint32_t (&t)[2]) {
 }
 template <int NW>
 __device__ __forceinline__ f32x4 k4_mfma(const uint4& a, const uint4& b, const f32x4& c) {
+#if K4_NO_MFMA      // timing experiment only (wrong results): what the fragment stream costs without the matrix work
+    f32x4 r = c; r[0] += __uint_as_float((a.x ^ b.x ^ b.y ^ b.z ^ b.w) & 0x3f800000u); return r;
+#endif
     if constexpr (NW == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else                   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), as_frag(b), c, 0, 0, 0);
 }

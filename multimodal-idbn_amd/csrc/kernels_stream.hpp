@@ -198,24 +198,21 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
 #pragma unroll
         for (int i = 0; i < 8; ++i) xs[i] = 0.f;
         const gu32* s0p = (const gu32*)(a.slabs + ((int64_t)z * a.ks * ntiles + tile) * 2048) + (8 * oct) * 32 + c;
-        int k = 0;
-        for (; k + 4 <= a.ks; k += 4) {                   // 32 loads in flight; summed strictly in slice order
-            uint32_t t[4][8];
+        // up to 8 slices per round trip (5 at the headline shape: ONE dependent batch of loads instead of 4 + 1; surplus slots
+        // re-read the last slice and are not added); summed strictly in slice order
+        for (int k = 0; k < a.ks; k += 8) {
+            uint32_t t[8][8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t[q][i] = __hip_atomic_load(s0p + (int64_t)(k + q) * ntiles * 2048 + i * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 8; ++i)
+                    t[q][i] = __hip_atomic_load(s0p + (int64_t)min(k + q, a.ks - 1) * ntiles * 2048 + i * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 8; ++q)
+                if (k + q < a.ks) {                           // block-uniform
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xs[i] = (k + q == 0) ? __uint_as_float(t[q][i]) : xs[i] + __uint_as_float(t[q][i]);
-        }
-        for (; k < a.ks; ++k) {
-            uint32_t t[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t[i] = __hip_atomic_load(s0p + (int64_t)k * ntiles * 2048 + i * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xs[i] = (k == 0) ? __uint_as_float(t[i]) : xs[i] + __uint_as_float(t[i]);
+                    for (int i = 0; i < 8; ++i) xs[i] = (k + q == 0) ? __uint_as_float(t[q][i]) : xs[i] + __uint_as_float(t[q][i]);
+                }
         }
     }
     stamp(st, sblk, 5);

@@ -735,7 +735,8 @@ bool chain_kernel_ok(const Ctx& c, int n_steps) {
     const int gw = c.d->n_groups ? c.d->group_end[0] - c.d->group_start[0] : 0;
     const size_t lds = (size_t)(c.nw == 3 ? 2 : 1) * K4_ROWS * ((rup(L.V, 32) + 8) + (rup(L.H, 32) + 8)) * 2      // activation terms
                      + (size_t)K4_ROWS * (rup(std::max(L.V, L.H), 16) + 1) * 4                        // fp32 stage
-                     + (size_t)K4_ROWS * (gw + 1) * 4 + K4_ROWS * 16;                                  // group logits, row stats
+                     + (size_t)K4_ROWS * (gw + 1) * 4 + K4_ROWS * 16                                   // group logits, row stats
+                     + (size_t)(K4_ROWS / 2) * gw * 2 * 4;                                             // group-column noise drawn ahead
     return gw <= GROUP_WMAX && lds <= (size_t)K4_LDS_BYTES;
 }
 

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     float* stage = reinterpret_cast<float*>(hact + at * K4_ROWS * HK);              // [16][SP] raw sums of the current half step
     float* glog = stage + K4_ROWS * SP;                                             // [16][GW] group logits
     float* gaux = glog + K4_ROWS * GW;                                              // [16][4] group max, sum, sampled index
+    float* gz = gaux + K4_ROWS * 4;                                                 // [8 row pairs][gwd][2] noise of the group columns, drawn ahead
     const int NTu = (a.H + 15) / 16, KBu = (a.V + 31) / 32, NTd = (a.V + 15) / 16, KBd = (a.H + 31) / 32;
 
     // v0 -> terms (pad columns and rows >= B are zero)
@@ -254,7 +255,19 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
         {
             const DrawSrc nz = k4_src(a, r.noise_h, a.H), un = k4_src(a, r.uni_h, a.H);
             // thread = (row pair, column): the pair's draws come from one Philox block each (common.hpp)
-            for (int i = tid; i < RP * a.H; i += K4_THREADS) {
+            // The noise of the softmax-group columns of the COMING v half step depends on nothing computed here: the threads this
+            // phase leaves idle (RP * H = 256 items on 512 threads with two rows per block) draw it now.  The v epilogue's
+            // 532 = 512 + 20 items then no longer pay a second round of Philox + Box-Muller for 20 threads (3.2 -> 1.9 us).
+            const int nh_items = RP * a.H, ng_items = (gwd > 0 && r.sigma > 0.f) ? RP * gwd : 0;
+            const DrawSrc nzv = k4_src(a, r.noise_v, a.V);
+            for (int i = tid; i < nh_items + ng_items; i += K4_THREADS) {
+                if (i >= nh_items) {
+                    const int j = i - nh_items, gp = j / gwd, gc = j - gp * gwd;
+                    float zz[2] = {0.f, 0.f};
+                    draw_normal_rows2(nzv, b0 + 2 * gp, a.B - 1, gs0 + gc, zz);
+                    gz[(gp * gwd + gc) * 2 + 0] = zz[0]; gz[(gp * gwd + gc) * 2 + 1] = zz[1];
+                    continue;
+                }
                 const int pr = i / a.H, col = i - pr * a.H;
                 float z2[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};
                 if (r.sigma > 0.f) draw_normal_rows2(nz, b0 + 2 * pr, a.B - 1, col, z2);
@@ -285,7 +298,10 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                 const int pr = i / a.V, col = i - pr * a.V;
                 const bool in_group = gwd > 0 && col >= gs0 && col < gs0 + gwd;
                 float z2[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};
-                if (r.sigma > 0.f) draw_normal_rows2(nz, b0 + 2 * pr, a.B - 1, col, z2);
+                if (r.sigma > 0.f) {
+                    if (in_group) { z2[0] = gz[(pr * gwd + (col - gs0)) * 2 + 0]; z2[1] = gz[(pr * gwd + (col - gs0)) * 2 + 1]; }   // drawn during the h epilogue
+                    else draw_normal_rows2(nz, b0 + 2 * pr, a.B - 1, col, z2);
+                }
                 if (vmode != 0 && !in_group) draw_uniform_rows<2>(un, b0 + 2 * pr, a.B - 1, col, u2);
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {

@@ -148,29 +148,41 @@ __device__ __forceinline__ void k4_put(bf16_t* act, int AK, int row, int col, fl
 #define K4_SKIP_LOLO 0      // 1 was measured in round 2: GEMM phases 7.44 -> 7.28 us only (not MFMA bound)
 #endif
 constexpr int K4_RING = 6;           // round 2: 9 (242 VGPRs, no spill) -> GEMM phases 7.8 / 8.4 us, 12 (spills) -> 8.7 us, against 7.4 / 7.8 with 6: not bound by the bytes in flight
-template <int NW, int NA>
-__device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB, const bf16_t* act, int AK,
-                                        float* stage, int SP) {
+// one B fragment item (tile nt, k-block kb) of the wave's flat item sequence, clamped (surplus slots repeat the last item)
+template <int NW>
+__device__ __forceinline__ void k4_load_item(const K4Args& a, int dir, int KB, int n_items, int it, uint4 (&b)[NW]) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const bf16_t* pl = a.planes + (int64_t)dir * 3 * a.plane_stride;
+    const int itc = max(min(it, n_items - 1), 0);
+    const int nt = w + K4_WAVES * (itc / KB), kb = itc - (itc / KB) * KB;
+#pragma unroll
+    for (int tw = 0; tw < NW; ++tw) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        const u32x4* q = reinterpret_cast<const u32x4*>(pl + tw * a.plane_stride + ((int64_t)(nt * KB + kb) * 64 + l) * 8);
+        const u32x4 x = K4_NT_LOADS ? __builtin_nontemporal_load(q) : *q;
+        b[tw] = make_uint4(x.x, x.y, x.z, x.w);
+    }
+}
+// The first K4_RING items of a GEMM do not depend on the activations: they are requested BEFORE the epilogue of the previous
+// half step (k4_chain), so that the ~1 us of L2 latency at the start of every GEMM hides behind the epilogue's Philox work.
+template <int NW>
+__device__ __forceinline__ void k4_prefetch(const K4Args& a, int dir, int NT, int KB, uint4 (&ring)[K4_RING][NW]) {
+    const int w = threadIdx.x >> 6;
     const int my_tiles = w < NT ? (NT - w + K4_WAVES - 1) / K4_WAVES : 0;
     const int n_items = my_tiles * KB;
-    uint4 ring[K4_RING][NW];
-    auto load = [&](uint4 (&b)[NW], int it) {
-        const int itc = min(it, n_items - 1);                            // clamped: surplus slots repeat the last item
-        const int nt = w + K4_WAVES * (itc / KB), kb = itc - (itc / KB) * KB;
-#pragma unroll
-        for (int tw = 0; tw < NW; ++tw)
-            {
-                typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-                const u32x4* q = reinterpret_cast<const u32x4*>(pl + tw * a.plane_stride + ((int64_t)(nt * KB + kb) * 64 + l) * 8);
-                const u32x4 x = K4_NT_LOADS ? __builtin_nontemporal_load(q) : *q;
-                b[tw] = make_uint4(x.x, x.y, x.z, x.w);
-            }
-    };
     if (n_items == 0) return;
 #pragma unroll
-    for (int d = 0; d < K4_RING; ++d) load(ring[d], d);
+    for (int d = 0; d < K4_RING; ++d) k4_load_item<NW>(a, dir, KB, n_items, d, ring[d]);
+}
+
+template <int NW, int NA>
+__device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB, const bf16_t* act, int AK,
+                                        float* stage, int SP, uint4 (&ring)[K4_RING][NW]) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int my_tiles = w < NT ? (NT - w + K4_WAVES - 1) / K4_WAVES : 0;
+    const int n_items = my_tiles * KB;
+    auto load = [&](uint4 (&b)[NW], int it) { k4_load_item<NW>(a, dir, KB, n_items, it, b); };
+    if (n_items == 0) return;                        // (`ring` was filled by k4_prefetch)
     f32x4 acc[NW];                   // one accumulator per weight term: NW independent MFMA chains instead of one of 3*NW
 #pragma unroll
     for (int tw = 0; tw < NW; ++tw) acc[tw] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -240,6 +252,8 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     __syncthreads();
 
     const int RP = (RB + 1) / 2;                                  // row pairs of the block
+    uint4 ring[K4_RING][NW];                                      // B-fragment ring of the GEMMs, pre-filled one phase ahead
+    k4_prefetch<NW>(a, 0, NTu, KBu, ring);
     for (int t = 0; t < a.n_steps; ++t) {
         const ChainRec r = a.recs[t];
         const bool st = a.dbg && t == 2;
@@ -249,7 +263,8 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
         const float T = fmaxf(r.T, 1e-6f);                       // max(1e-6, T)  rbm.py:92,96
         const bool pull_on = a.mu && r.eta != 0.f;
         // ---- h | v  (rbm.py:81-92) -----------------------------------------------------------------
-        k4_gemm<NW, NW>(a, 0, NTu, KBu, vact, VK, stage, SP);
+        k4_gemm<NW, NW>(a, 0, NTu, KBu, vact, VK, stage, SP, ring);
+        k4_prefetch<NW>(a, 1, NTd, KBd, ring);                    // the v|h GEMM's first fragments travel during the h epilogue
         __syncthreads();
         stamp(st, blockIdx.x, 1);
         {
@@ -288,8 +303,9 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
         __syncthreads();
         stamp(st, blockIdx.x, 2);
         // ---- v | h  (rbm.py:94-135) ------------------------------------------------------------------
-        if (sample_h) k4_gemm<NW, 1>(a, 1, NTd, KBd, hact, HK, stage, SP);      // sampled states are exactly bf16: one term
-        else          k4_gemm<NW, NW>(a, 1, NTd, KBd, hact, HK, stage, SP);
+        if (sample_h) k4_gemm<NW, 1>(a, 1, NTd, KBd, hact, HK, stage, SP, ring);      // sampled states are exactly bf16: one term
+        else          k4_gemm<NW, NW>(a, 1, NTd, KBd, hact, HK, stage, SP, ring);
+        if (!last) k4_prefetch<NW>(a, 0, NTu, KBu, ring);         // the next step's h|v GEMM: during the v epilogue and the group passes
         __syncthreads();
         stamp(st, blockIdx.x, 3);
         {

@@ -181,8 +181,27 @@ __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int my_tiles = w < NT ? (NT - w + K4_WAVES - 1) / K4_WAVES : 0;
     const int n_items = my_tiles * KB;
-    auto load = [&](uint4 (&b)[NW], int it) { k4_load_item<NW>(a, dir, KB, n_items, it, b); };
     if (n_items == 0) return;                        // (`ring` was filled by k4_prefetch)
+    // The loads after the prefetched ones walk the item sequence with INCREMENTAL, wave-uniform address arithmetic: consecutive
+    // k-blocks of a tile are 1 KB apart, the wave's next tile 8 KB tiles further.  (Recomputing tile and k-block of every item
+    // from its index -- a division by the run-time KB per item -- kept the item loop busy with integer work: see DESIGN 9.3.)
+    const char* pl = reinterpret_cast<const char*>(a.planes + (int64_t)dir * 3 * a.plane_stride) + l * 16;
+    int lit = min(K4_RING, n_items - 1);                                 // item the next load fetches (clamped to the last one)
+    int lkb = lit % KB;
+    int64_t loff = ((int64_t)(w + K4_WAVES * (lit / KB)) * KB + lkb) * 1024;        // byte offset of that item inside a plane
+    auto load = [&](uint4 (&b)[NW]) {
+#pragma unroll
+        for (int tw = 0; tw < NW; ++tw) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+            const u32x4 x = *reinterpret_cast<const u32x4*>(pl + tw * a.plane_stride * 2 + loff);
+            b[tw] = make_uint4(x.x, x.y, x.z, x.w);
+        }
+        if (lit + 1 < n_items) {                                          // wave-uniform; past the end the last item is re-read (L2 hits)
+            ++lit;
+            if (++lkb == KB) { lkb = 0; loff += (int64_t)((K4_WAVES - 1) * KB + 1) * 1024; }
+            else loff += 1024;
+        }
+    };
     f32x4 acc[NW];                   // one accumulator per weight term: NW independent MFMA chains instead of one of 3*NW
 #pragma unroll
     for (int tw = 0; tw < NW; ++tw) acc[tw] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -204,7 +223,7 @@ __device__ __forceinline__ void k4_gemm(const K4Args& a, int dir, int NT, int KB
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            load(ring[d], it0 + d + K4_RING);
+            load(ring[d]);
             if (++kb == KB) {                                             // tile finished (padding items never get here with a real tile)
                 if (it0 + d < n_items) {
 #pragma unroll

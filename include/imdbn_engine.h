@@ -102,6 +102,8 @@ typedef struct imdbn_chain_step {
     int32_t clamp;          /* 1: v = v*(1-mask) + v_known*mask (masks must be 0/1) */
 } imdbn_chain_step;
 
+enum { IMDBN_DATA_UNKNOWN = 0, IMDBN_DATA_BINARY = 1, IMDBN_DATA_REAL = 2 };      /* imdbn_cd_opts.data_binary / next_binary */
+
 /* Options of one CD update (rbm.py:181-227, :403-483). */
 typedef struct imdbn_cd_opts {
     int32_t cd_k;           /* Gibbs steps of the negative phase (>=1) */
@@ -122,13 +124,18 @@ typedef struct imdbn_cd_opts {
     int64_t ld_next;
     int32_t next_slot;      /* 1 or 2: where to put it (must differ from data_slot) */
     int32_t data_slot;      /* 0: prepare `data` now (default); 1 / 2: `data` was prefetched into that slot */
-    /* -- 1: the caller asserts that every element of `data` is exactly 0 or 1 (binary images): the positive phase then reads
-     * the batch as a bit plane (imdbn_rbm_cd_step / _cd_stats / _cd_factors).  The assertion is checked on the device; a batch
-     * that is not binary turns the update into NaN instead of being silently truncated.  0: no assumption. */
+    /* -- what the caller knows about the VALUES of `data` (IMDBN_DATA_*).  Nothing has to be known: with IMDBN_DATA_UNKNOWN (0)
+     * the device decides, per 64-column piece of the batch and from the exactness map its own preparation kernel writes, whether the
+     * positive phase reads that piece as a bit plane (all values 0 / 1: binary images) or as bf16 terms; the result is the same
+     * number either way, so the caller never has to inspect a batch (no device reduction, no host synchronisation).
+     * IMDBN_DATA_BINARY (1): the caller asserts every element is exactly 0 or 1; the assertion is checked on the device and a
+     * batch that is not binary turns the update into NaN instead of being silently truncated.  IMDBN_DATA_REAL (2): real values
+     * (the output of another layer): no bit plane is made. */
     int32_t data_binary;
-    /* -- 1: the same assertion for `next_data`: its preparation then writes only what a binary batch needs (bit plane,
-     * exactness map, column sums, one bf16 plane) instead of all three-term operand forms.  Honoured only when the positive
-     * phase can read bit planes (16-B aligned weight rows, V > 1024); the later cd_step on that batch must pass data_binary = 1. */
+    /* -- the same for `next_data`.  UNKNOWN: every 64-column x 64-row piece that turns out to be all 0 / 1 is prepared in the slim
+     * form (bit plane, exactness map, column sums, one bf16 plane), any other piece with all three-term operand forms; BINARY: the
+     * slim form throughout.  Honoured where the positive phase can read bit planes (16-B aligned weight rows, V > 1024); the later
+     * cd_step on that batch must pass the same value in data_binary. */
     int32_t next_binary;
     /* -- forward pass fused behind the update (imdbn_rbm_cd_step only; NULL = off): after the weights are updated, the
      * hidden probabilities sigmoid(data @ W + hid_bias) of the SAME batch under the NEW weights are written to
@@ -180,9 +187,10 @@ int imdbn_rbm_prop_up(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int 
                       imdbn_rng* rng, float* out_prob, int64_t ldo, float* out_sample, int64_t lds,
                       void* ws, size_t ws_bytes, imdbn_stream_t stream);
 
-/* forward(v) at T = 1: out_prob[B][H] = sigmoid(v W + c).  data_binary = 1: the caller asserts v is 0/1 (checked on the
- * device, NaN on a false promise): the batch is then read as a bit plane by the streaming K1.  Bit-identical to the fused
- * forward of imdbn_rbm_cd_step (imdbn_cd_opts.fwd_out) for the same batch, weights and data_binary. */
+/* forward(v) at T = 1: out_prob[B][H] = sigmoid(v W + c).  data_binary = IMDBN_DATA_* as in imdbn_cd_opts (UNKNOWN: the device
+ * reads every 64-column piece of v as a bit plane or as bf16 terms, whichever describes it; BINARY: asserted, checked, NaN on a
+ * false promise).  Bit-identical to the fused forward of imdbn_rbm_cd_step (imdbn_cd_opts.fwd_out) for the same batch and
+ * weights, whatever data_binary says. */
 int imdbn_rbm_forward(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int B, int data_binary,
                       float* out_prob, int64_t ldo, void* ws, size_t ws_bytes, imdbn_stream_t stream);
 

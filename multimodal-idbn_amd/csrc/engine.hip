@@ -47,6 +47,8 @@ struct Tuning {
     int k1s_ks = 0;                  // tuning: K slices of k1_stream (0 = automatic)
     int no_k2s = 0;                  // testing: never use k2_stream (the fused K2 for a bit-plane hidden operand, one tile per CU)
     int k2s_tr = 0;                  // tuning: rows per k2_stream block (0 = automatic; multiple of 8, <= 48)
+    int no_k1s_real = 0;             // testing: real-valued operands of K1 take the partial GEMM + finish launches, not k1_stream
+    int no_adaptive = 0;             // testing: a prefetched batch of unknown content gets all three-term forms (no per-item choice)
 };
 Tuning g_defaults;
 thread_local const Tuning* t_bound = nullptr;
@@ -68,6 +70,8 @@ inline const Tuning& tune() { return t_bound ? *t_bound : g_defaults; }
 #define g_k1s_ks (tune().k1s_ks)
 #define g_no_k2s (tune().no_k2s)
 #define g_k2s_tr (tune().k2s_tr)
+#define g_no_k1s_real (tune().no_k1s_real)
+#define g_no_adaptive (tune().no_adaptive)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
@@ -305,6 +309,8 @@ struct Ctx {
     bool hid_bits_ok = false;      // L.hid_bits describes the current contents of L.hid_rm
     bool data_prepped = false;     // cd_phases: the data-side operands are already in place (prefetch slot)
     int down_blocks = 0;           // blocks (per batch chunk) of the last K2 launch: the number of squared-error partials it left
+    bool fix_slot = false;         // the data-side operands were written item by item (PrepArgs::adaptive): the next k1_stream that reads them
+                                   // completes the planes of mixed spans for the update kernel (K1sArgs::fix_tr)
     Ctx(const imdbn_rbm_desc* d_, imdbn_rng* r, hipStream_t s_) : d(d_), s(s_), rng(r) {
         nw = d->mode == IMDBN_FAST_BF16 ? 1 : 3;
         rt = nw;
@@ -355,8 +361,15 @@ int setup(Ctx& c, int B, void* ws, size_t ws_bytes) {
 
 // An activation operand in row-major form: pointer + static term count (0 = look at flag)
 // bits / binary: the operand also exists as a bit plane; binary = 1: it is 0/1 by construction (a sample), 2: the caller
-// says so (checked on the device against the exactness map `flag`)
+// says so (checked on the device against the exactness map `flag`), 3: nobody knows -- the streaming K1 decides per
+// 64-column item from the exactness map (bit plane where the item is all 0/1, the bf16 terms in `rm` elsewhere)
 struct OpIn { const bf16_t* rm; int terms; const int* flag; const uint8_t* bits = nullptr; int binary = 0; };
+
+// visible tiles (128 rows) per block of the streaming update kernel
+int k3_tiles_per_block(int V, int H) {
+    const int nh = cdiv(H, 128), nv = cdiv(V, 128);
+    return std::max(1, cdiv(nh * nv, std::max(cu_count(), 1)));
+}
 
 bool vec4_weights(const imdbn_rbm_desc* d) {
     return d->H % 4 == 0 && d->H >= 4 && d->ldw % 4 == 0 && (((uintptr_t)d->W) & 15) == 0;
@@ -415,23 +428,41 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         HIPCHK(hipGetLastError());
         return 0;
     }
-    if (up && in.bits && in.binary && vec4_weights(d) && !g_no_k1s && !f.logits_only) {
-        // binary visible operand: weights stream through LDS by LDS-DMA, split-K combined by the last arriver, epilogue fused
+    // streaming K1: weights through LDS by LDS-DMA, split-K combined by the last arriver, epilogue fused.  The operand is a bit
+    // plane (0/1 by construction or by the caller's word), bf16 terms (real values), or either per 64-column item (unknown)
+    const bool k1s_bits = in.bits && (in.binary == 1 || in.binary == 2);
+    const bool k1s_real = !k1s_bits && in.rm && !g_no_k1s_real && (in.binary == 0 || (in.binary == 3 && in.bits && in.flag));
+    if (up && (k1s_bits || k1s_real) && vec4_weights(d) && !g_no_k1s && !f.logits_only) {
         K1sArgs a;
         memset(&a, 0, sizeof(a));
         a.W = d->W; a.ldw = d->ldw; a.K = L.V; a.N = L.H;
         a.abits = in.bits; a.Bp = L.Bp;
-        a.aflag = in.binary == 2 ? in.flag : nullptr; a.ncb = cdiv(L.Vpad, 64); a.P = L.P;
+        a.aflag = in.binary >= 2 ? in.flag : nullptr; a.ncb = cdiv(L.Vpad, 64); a.P = L.P;
         a.slabs = L.partial; a.counters = L.k1s_cnt; a.kchunk = L.k1s_kchunk; a.ks = L.k1s_ks;
+        a.amode = k1s_bits ? (in.binary == 2 ? K1S_ASSERTED : K1S_BITS) : (in.binary == 3 ? K1S_ADAPTIVE : K1S_REAL);
+        a.arm = in.rm; a.arm_ts = (int64_t)L.Bp * L.Vpad;
+        if (a.amode == K1S_ADAPTIVE && c.fix_slot && in.rm == L.vis_rm[0]) {
+            const int tpb = k3_tiles_per_block(L.V, L.H);
+            a.fix_tr = L.vis_tr[0]; a.fix_ts = (int64_t)L.V * L.Bp; a.fix_span = 2 * tpb; a.fix_ranges = cdiv(cdiv(L.V, 128), tpb);
+            if (a.fix_ranges > L.k1s_tiles * a.ks) return fail(IMDBN_E_INVALID, "internal: k1_stream fix-up ranges");
+            c.fix_slot = false;
+        }
+        // terms the kernel multiplies per element: the operand form carries `in.terms` of them (0 = prep's three, nw in FAST mode)
+        const int na = k1s_bits ? 0 : ((in.terms == 1 || c.nw == 1) ? 1 : 3);
         f.dbg = g_dbg;
         f.op.bits = want_hbits ? L.hid_bits : nullptr; f.op.bits_shape = 1; f.op.bits_cols = 32;
         if (f.op.rm == L.hid_rm) c.hid_bits_ok = want_hbits;
         if (want_hbits && !g_no_bits) f.op.rm = nullptr, f.rm_src = 0;      // the fused K2 reads the bit plane, nobody reads the bf16 form
-        const size_t lds = (size_t)4 * K1S_RING + (size_t)8 * a.kchunk;      // 80 KB at the headline shape: two workgroups per CU
+        // 80 KB at the headline shape: two workgroups per CU (the bit-plane kernel carries the next batch's preparation blocks)
+        const size_t lds = na > 0 ? (size_t)4 * K1S_REGION_REAL + (size_t)8 * a.kchunk + K1S_LDS_EXTRA : (size_t)4 * K1S_RING + (size_t)8 * a.kchunk;
         static bool attr_done = false;
         if (!attr_done) {
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK));
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_RING + 8 * K1S_MAX_KCHUNK));
+            const int mx = 4 * K1S_REGION_REAL + 8 * K1S_MAX_KCHUNK + K1S_LDS_EXTRA;
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
             attr_done = true;
         }
         f.lean = lean_ok(f);
@@ -441,8 +472,15 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         const int items = next ? cdiv(std::max(next->N, next->op.ldrm), 64) : 0;
         const int pr = next ? std::min(8, cdiv(items, L.k1s_tiles)) : 0;
         dim3 grid(L.k1s_tiles, a.ks + pr, mb);
-        if (c.nw == 3) hipLaunchKernelGGL(k1_stream<3>, grid, dim3(256), lds, c.s, a, f, next ? *next : pz);
-        else           hipLaunchKernelGGL(k1_stream<1>, grid, dim3(256), lds, c.s, a, f, next ? *next : pz);
+        const PrepArgs& pa = next ? *next : pz;
+        if (c.nw == 3) {
+            if (na == 0)      hipLaunchKernelGGL((k1_stream<3, 0>), grid, dim3(256), lds, c.s, a, f, pa);
+            else if (na == 1) hipLaunchKernelGGL((k1_stream<3, 1>), grid, dim3(256), lds, c.s, a, f, pa);
+            else              hipLaunchKernelGGL((k1_stream<3, 3>), grid, dim3(256), lds, c.s, a, f, pa);
+        } else {
+            if (na == 0)      hipLaunchKernelGGL((k1_stream<1, 0>), grid, dim3(256), lds, c.s, a, f, pa);
+            else              hipLaunchKernelGGL((k1_stream<1, 1>), grid, dim3(256), lds, c.s, a, f, pa);
+        }
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -659,6 +697,9 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
     return 0;
 }
 
+// imdbn_cd_opts.data_binary (0 unknown, 1 asserted 0/1, 2 real) -> OpIn::binary of the data operand
+int data_operand_kind(int data_binary) { return data_binary == IMDBN_DATA_BINARY ? 2 : (data_binary == IMDBN_DATA_UNKNOWN ? 3 : 0); }
+
 // rbm.py:199-209: positive phase, CD-k Gibbs, statistics left in the workspace operand buffers.
 int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, const PrepArgs* next = nullptr) {
     const Layout& L = c.L;
@@ -678,7 +719,7 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
         f.op.rm = L.hid_rm; f.op.rm_terms = 1; f.rm_src = 2;
         f.op.tr = L.hid_tr[0]; f.op.tr_terms = c.ht; f.tr_src = 1;
         f.colsum_part = L.cs_hpos; f.colsum_src = 1;
-        CHK(prop(c, true, OpIn{L.vis_rm[0], c.nw == 1 ? 1 : 0, L.flags, L.vis_bits[0], o->data_binary ? 2 : 0}, f));
+        CHK(prop(c, true, OpIn{L.vis_rm[0], c.nw == 1 ? 1 : 0, L.flags, L.vis_bits[0], data_operand_kind(o->data_binary)}, f));
     }
     for (int it = 0; it < o->cd_k; ++it) {
         const bool last = (it == o->cd_k - 1);
@@ -910,6 +951,8 @@ static int set_opt(Tuning& t, const char* name, int value) {
     else if (!strcmp(name, "no_k2s")) t.no_k2s = value;
     else if (!strcmp(name, "k2s_rows")) { if (value != 0 && (value < 8 || value > 48 || value % 8)) return fail(IMDBN_E_INVALID, "k2s_rows must be 0 or a multiple of 8 in [8, 48]"); t.k2s_tr = value; }
     else if (!strcmp(name, "generic_k1")) t.no_fast_k1 = value != 0;
+    else if (!strcmp(name, "no_k1s_real")) t.no_k1s_real = value;
+    else if (!strcmp(name, "no_adaptive")) t.no_adaptive = value;
     else if (!strcmp(name, "no_fused_up")) t.no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);
     return 0;
@@ -1014,11 +1057,13 @@ int imdbn_rbm_forward(const imdbn_rbm_desc* d, const float* v, int64_t ldv, int 
     if (!v || !out_prob || ldv < d->V || ldo < d->H) return fail(IMDBN_E_INVALID, "forward: bad tensor argument");
     Ctx c(d, nullptr, S(stream));
     CHK(setup(c, B, ws, ws_bytes));
-    const bool bits = data_binary && vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024;       // prop() then launches k1_stream
-    CHK(prep(c, v, ldv, d->V, bits ? nullptr : c.L.vis_rm[0], c.L.Vpad, nullptr, c.L.flags, nullptr, 3, bits ? c.L.vis_bits[0] : nullptr));
+    if (data_binary < 0 || data_binary > 2) return fail(IMDBN_E_INVALID, "forward: data_binary %d", data_binary);
+    const bool k1s = vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024;       // prop() then launches k1_stream
+    const bool bits = k1s && data_binary != IMDBN_DATA_REAL, only_bits = k1s && data_binary == IMDBN_DATA_BINARY;
+    CHK(prep(c, v, ldv, d->V, only_bits ? nullptr : c.L.vis_rm[0], c.L.Vpad, nullptr, c.L.flags, nullptr, 3, bits ? c.L.vis_bits[0] : nullptr));
     FinishArgs f = new_finish();
     f.out_prob = out_prob; f.ld_prob = ldo;
-    CHK(prop(c, true, OpIn{c.L.vis_rm[0], c.nw == 1 ? 1 : 0, c.L.flags, bits ? c.L.vis_bits[0] : nullptr, bits ? 2 : 0}, f));
+    CHK(prop(c, true, OpIn{c.L.vis_rm[0], c.nw == 1 ? 1 : 0, c.L.flags, bits ? c.L.vis_bits[0] : nullptr, bits ? data_operand_kind(data_binary) : 0}, f));
     return 0;
 }
 
@@ -1115,20 +1160,24 @@ static int cd_prologue(Ctx& c, const imdbn_cd_opts* o, PrepArgs& pn, bool& rides
         pn.op.tr = L.pf_tr[t]; pn.op.tr_ts = (int64_t)L.V * L.Bp; pn.op.tr_terms = 3;
         pn.flag = L.pf_flags[t]; pn.colsum_part = L.pf_cs[t];
         pn.op.bits = L.pf_bits[t]; pn.op.bits_shape = 0;
-        if (allow_compact && o->next_binary && vec4_weights(d) && !g_no_k1s && L.Vpad > 1024) {
-            // a 0/1 batch: the positive phase reads the bit plane, the update kernel one bf16 plane (the exactness map says "one term")
-            pn.op.rm = nullptr; pn.op.rm_terms = 0; pn.op.tr_terms = 1;
-        }
     }
     // Where the next batch is prepared: as extra blocks of the fused K2 (gemm_down_fused_next) or of the negative-phase
     // k1_stream (cd_phases decides); where neither can carry them, a prep_operand launch of its own, first thing.
     rides = next_rows > 0 && (!k2s_for_cd(d) || (d->n_groups == 0 && vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024));
+    if (next_rows > 0 && allow_compact && vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024) {
+        if (o->next_binary == IMDBN_DATA_BINARY) {
+            // a 0/1 batch: the positive phase reads the bit plane, the update kernel one bf16 plane (the exactness map says "one term")
+            pn.op.rm = nullptr; pn.op.rm_terms = 0; pn.op.tr_terms = 1;
+        } else if (o->next_binary == IMDBN_DATA_UNKNOWN && rides && !g_no_adaptive && !g_no_k1s_real) {
+            pn.adaptive = 1;      // the same slim set for every 64-column item that turns out to be all 0/1, decided by the preparing block
+        }
+    }
     if (next_rows > 0 && !rides) {
         pn.zero = nullptr; pn.n_zero = 0;
         hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(pn.N, pn.op.ldrm), 64), c.L.P), dim3(256), 0, c.s, pn);
         HIPCHK(hipGetLastError());
     }
-    if (o->data_slot) { use_slot(c.L, o->data_slot); c.data_prepped = true; }
+    if (o->data_slot) { use_slot(c.L, o->data_slot); c.data_prepped = true; c.fix_slot = o->data_binary == IMDBN_DATA_UNKNOWN; }
     return 0;
 }
 
@@ -1136,6 +1185,7 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
                       imdbn_rng* rng, float* loss_out, void* ws, size_t ws_bytes, imdbn_stream_t stream) {
     CHK(check_desc(d, true));
     if (!data || !o || ldd < d->V) return fail(IMDBN_E_INVALID, "cd_step: bad argument");
+    if (o->data_binary < 0 || o->data_binary > 2 || o->next_binary < 0 || o->next_binary > 2) return fail(IMDBN_E_INVALID, "cd_step: data_binary / next_binary outside 0..2");
     Ctx c(d, rng, S(stream));
     CHK(setup(c, B, ws, ws_bytes));
     PrepArgs pn;
@@ -1151,8 +1201,8 @@ int imdbn_rbm_cd_step(const imdbn_rbm_desc* d, const float* data, int64_t ldd, i
         if (o->ld_fwd < d->H) return fail(IMDBN_E_INVALID, "cd_step: ld_fwd %lld < H %d", (long long)o->ld_fwd, d->H);
         FinishArgs f = new_finish();
         f.out_prob = o->fwd_out; f.ld_prob = o->ld_fwd;
-        const bool bits = o->data_binary && vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024;      // as imdbn_rbm_forward
-        CHK(prop(c, true, OpIn{c.L.vis_rm[0], c.nw == 1 ? 1 : 0, c.L.flags, bits ? c.L.vis_bits[0] : nullptr, bits ? 2 : 0}, f));
+        const bool bits = o->data_binary != IMDBN_DATA_REAL && vec4_weights(d) && !g_no_k1s && c.L.Vpad > 1024;      // as imdbn_rbm_forward
+        CHK(prop(c, true, OpIn{c.L.vis_rm[0], c.nw == 1 ? 1 : 0, c.L.flags, bits ? c.L.vis_bits[0] : nullptr, bits ? data_operand_kind(o->data_binary) : 0}, f));
     }
     return 0;
 }

@@ -586,6 +586,10 @@ struct PrepArgs {
                                    // 3 bf16 terms, bit 1 = some element is neither 0 nor 1 (the bit plane op.bits does not describe it)
     float* colsum_part;            // [Bp/8][N] column sums over each 8-row group (sum data, rbm.py:223)
     int* zero; int n_zero;         // words block (0,0) of prep_operand clears (arrival counters of the split-K kernels of this call)
+    int adaptive;                  // prep_item_* only: decide PER ITEM (64 columns x 64 rows) on the device what a batch of unknown content
+                                   // needs -- an item whose values are all 0 / 1 leaves as bit plane + ONE bf16 plane (what the streaming K1
+                                   // and the update kernel read of it), any other item with all three-term forms.  Nothing on the host has
+                                   // to know (or ask: a device reduction + sync per fresh tensor) whether a batch is binary.
 };
 constexpr int FLAG_INEXACT = 1, FLAG_NONBINARY = 2;
 
@@ -666,6 +670,22 @@ __device__ __forceinline__ void prep_item_process(const PrepArgs& a, int tx, int
     const int ntx = (max(a.N, a.op.ldrm) + 63) / 64;
     const int col = tx * 64 + c;
     const RmStage stg{rmst, 4, 64, tx * 64, mb * 64};
+    // adaptive: the item's forms follow its content (block-wide OR of "some value is neither 0 nor 1"; the four words sit
+    // behind the 24 KB stage, the caller's barrier after the item protects their reuse)
+    OperandOut op = a.op;
+    if (a.adaptive) {
+        bool nb = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float x = (col < a.N && mb * 64 + 16 * kq + i < a.B) ? v[i] : 0.f;
+            nb |= (x != 0.f && x != 1.0f);
+        }
+        int* sw = reinterpret_cast<int*>(rmst + 3 * 4 * 64 * 16);
+        const bool anyb = __any(nb ? 1 : 0) != 0;
+        if (c == 0) sw[kq] = anyb ? 1 : 0;
+        lds_barrier();
+        if (!(sw[0] | sw[1] | sw[2] | sw[3])) { op.rm = nullptr; op.rm_terms = 0; op.tr_terms = 1; }
+    }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         const int b0 = mb * 64 + 16 * kq + 8 * hf, by = b0 >> 3;
@@ -676,18 +696,18 @@ __device__ __forceinline__ void prep_item_process(const PrepArgs& a, int tx, int
             x[i] = (col < a.N && b0 + i < a.B) ? v[8 * hf + i] : 0.f;
             inexact |= (__float_as_uint(x[i]) & 0xFFFFu) != 0u;
             nonbin |= (x[i] != 0.f && x[i] != 1.0f);
-            if (a.op.bits) store_bits_row(a.op, x[i] != 0.f, col, b0 + i, true, 0, 64);
+            if (op.bits) store_bits_row(op, x[i] != 0.f, col, b0 + i, true, 0, 64);
         }
         // the order of prep_operand: four row pairs, combined left to right
         const float csum = (((0.f + x[0] + x[1]) + (0.f + x[2] + x[3])) + (0.f + x[4] + x[5])) + (0.f + x[6] + x[7]);
         const bool any = __any(inexact ? 1 : 0) != 0, anyb = __any(nonbin ? 1 : 0) != 0;      // the wave = this group's 64 columns
-        store_forms<8>(a.op, x, true, true, b0, col, a.N, a.Bp, stg);
+        store_forms<8>(op, x, true, true, b0, col, a.N, a.Bp, stg);
         if (a.flag && c == 0) a.flag[by * ntx + tx] = (any ? FLAG_INEXACT : 0) | (anyb ? FLAG_NONBINARY : 0);
         if (a.colsum_part && col < a.N) a.colsum_part[(int64_t)by * a.N + col] = csum;
     }
-    if (a.op.rm) {                    // the K16-blocked form leaves through the LDS stage (block-uniform)
+    if (op.rm) {                    // the K16-blocked form leaves through the LDS stage (block-uniform)
         lds_barrier();
-        flush_rm_stage(a.op, stg);
+        flush_rm_stage(op, stg);
     }
 }
 

@@ -28,7 +28,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 constexpr int K1S_D = 4;                          // ring slots per wave; a slot = 2 K16 steps = 4 instructions = 32 rows x 128 B
 constexpr int K1S_RING = K1S_D * 4 * 1024;        // 16 KB per wave
-constexpr int K1S_MAX_KCHUNK = 8192;              // LDS: 64 KB of rings + 8 B per K row of activation bits
+constexpr int K1S_REGION_REAL = 32 * 1024;        // per-wave LDS of the kernels that can read bf16 terms: weight ring (6 K16 steps, 12 KB) + A ring (3 steps x 2 NA KB)
+constexpr int K1S_WSTEPS = 6, K1S_ASTEPS = 3;     // ring depths (K16 steps) of that loop
+constexpr int K1S_MAX_KCHUNK = 3840;              // LDS: rings + 8 B per K row of activation bits (4 x 32 KB + 30 KB + mask words < 160 KB)
+constexpr int K1S_LDS_EXTRA = 64;                 // item-mask words behind the bits (adaptive operands)
+
+// How the activation operand of k1_stream is read (K1sArgs::amode).  Whatever the mode, a K16 step multiplies the same
+// fragments in the same order -- for a 0/1 value the bit plane and the first bf16 term are the same number and the further
+// terms are exact zeros -- so the result does not depend on which mode (or which per-item choice) served an element: the
+// choice is speed only, and nothing on the host has to know what a batch contains.
+constexpr int K1S_BITS = 0;        // 0/1 by construction (a sample): the bit plane
+constexpr int K1S_ASSERTED = 1;    // the caller says 0/1: the bit plane; checked against the exactness map, NaN when false
+constexpr int K1S_ADAPTIVE = 2;    // unknown content: per 64-column item the bit plane (item all 0/1 by the exactness map) or the bf16 terms
+constexpr int K1S_REAL = 3;        // real values: the bf16 terms (K16-blocked operand form), no bit plane
 
 struct K1sArgs {
     const float* W; int64_t ldw; int K, N;        // W[K][ldw] fp32, N valid columns (K = visible, N = hidden units)
@@ -37,6 +49,12 @@ struct K1sArgs {
     float* slabs;                                 // [Bp/64][ks][tiles][64][32] partial sums
     int* counters;                                // [Bp/64][tiles] arrival counters, zero at launch, zero again at exit
     int kchunk, ks;                               // rows per K slice (multiple of 64), number of slices
+    int amode;                                    // K1S_*
+    const bf16_t* arm; int64_t arm_ts;            // K16-blocked operand form [term][ceil(K/16)][Bp][16] (ADAPTIVE: valid for non-binary items)
+    // ADAPTIVE operands written item by item (prep_item_process, PrepArgs::adaptive): an all-0/1 item has ONE transposed plane, but
+    // the update kernel decides 1 or 3 planes per block over `fix_span` items -- where a span mixes both kinds, the binary items'
+    // planes 1, 2 are zeroed here (what a three-term split of 0/1 values is).  Cold path; nullptr = off.
+    bf16_t* fix_tr; int64_t fix_ts; int fix_span, fix_ranges;
 };
 
 // `next` / block rows >= a.ks: the launch can carry the preparation of the NEXT batch of the training loop (prep_item_body:
@@ -44,15 +62,22 @@ struct K1sArgs {
 // and exactly half of a CU's LDS (64 KB of rings + 16 KB of bits at the headline shape): a second workgroup fits beside each
 // streaming one, so the extra blocks start at once and are gone a few us into the launch.  (The update kernel's idle CUs were
 // tried first: under its read + write stream the same work took 25-45 us longer than the kernel itself.)
-template <int NW>
+//
+// NA = 0: bit-plane operands only (K1S_BITS / K1S_ASSERTED).  NA = 1 / NW: the kernel can also read NA bf16 terms per element
+// (K1S_ADAPTIVE / K1S_REAL): the A fragments of a K16 step are 2 NA contiguous KB of the K16-blocked form (L2-resident) and travel
+// by LDS-DMA into a second per-wave ring beside the weight ring -- no registers, every wait hand-counted (register loads written
+// in inline asm were tried: the compiler moves their destination registers around before the wait that makes them valid; plain
+// loads make it wait vmcnt(0) at every use beside LDS-DMA).  A block whose K slice holds only 0/1 items runs the bit-plane loop.
+template <int NW, int NA>
 __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const FinishArgs fa, const PrepArgs next) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 rings][activation bits]; no static LDS (keeps the base 16-B aligned)
+    constexpr bool REAL = NA > 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 rings][activation bits][mask words]; no static LDS (keeps the base 16-B aligned)
     if ((int)blockIdx.y >= a.ks) {
         const int nworkers = (gridDim.y - a.ks) * gridDim.x, wid = (blockIdx.y - a.ks) * gridDim.x + blockIdx.x;
         const int ntx = (max(next.N, next.op.ldrm) + 63) / 64;
         for (int it = wid; it < ntx; it += nworkers) {
             prep_item_body(next, it, blockIdx.z, reinterpret_cast<bf16_t*>(smem));
-            if (next.op.rm) lds_barrier();
+            if (next.op.rm || next.adaptive) lds_barrier();
         }
         return;
     }
@@ -64,16 +89,41 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     const int nsteps = (k_end - k0) / 16;                 // K16 steps of this slice; wave w takes steps w, w + 4, ...
     const int my_steps = (nsteps - w + 3) / 4;
     const int n_slots = (my_steps + 1) / 2;
-    char* ring = smem + w * K1S_RING;
-    const uint8_t* abl = reinterpret_cast<const uint8_t*>(smem + 4 * K1S_RING);      // [kchunk/8][64] bytes
+    constexpr int REGION = REAL ? K1S_REGION_REAL : K1S_RING;      // LDS per wave
+    char* ring = smem + w * REGION;
+    const uint8_t* abl = reinterpret_cast<const uint8_t*>(smem + 4 * REGION);      // [kchunk/8][64] bytes
+    uint32_t* smask = reinterpret_cast<uint32_t*>(smem + 4 * REGION + 8 * a.kchunk);      // [4 waves][4 words]
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)ring);
-    const uint32_t abl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem) + 4 * K1S_RING;
+    const uint32_t abl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem) + 4 * REGION;
 
     const bool st = (fa.dbg & 64) != 0;                   // tuning aid: per-block timeline (tools/stamps_probe.py)
     const int sblk = (z * gridDim.y + sl) * ntiles + tile;
     stamp(st, sblk, 0);
+    const int cb0 = k0 / 64, cb1 = min((k_end + 63) / 64, a.ncb), wd = cb1 - cb0;      // 64-column items of this slice
+    // ---- ADAPTIVE: the exactness-map entries of the slice's items, requested first (oldest in the in-order vmcnt queue: they
+    // have landed when the bits have).  Thread (p = tid >> 5, j = tid & 31) holds row group p of items j, 32 + j, ...; hand-written
+    // loads: the compiler's own wait for them would also cover part of the weight ring issued below.
+    uint32_t fl[4] = {0u, 0u, 0u, 0u};
+    const bool adaptive = REAL && a.amode == K1S_ADAPTIVE;
+    if (adaptive) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int* fp = a.aflag + (int64_t)(z * 8 + (tid >> 5)) * a.ncb + min(cb0 + 32 * q + (tid & 31), a.ncb - 1);
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(fl[q]) : "v"(fp) : "memory");
+        }
+    }
+    // the entries the update kernel will OR for one of its blocks (fix_span items x all row groups): requested now, looked at
+    // after the K loop
+    int fixbits = 0;
+    const int fix_r = sl * ntiles + tile;
+    const bool fixer = REAL && adaptive && a.fix_tr && z == 0 && fix_r < a.fix_ranges;
+    if (fixer) {
+        const int i0 = fix_r * a.fix_span, nitem = min(a.fix_span, a.ncb - i0);
+        for (int i = tid; i < nitem * a.P; i += 256) fixbits |= a.aflag[(i / nitem) * a.ncb + i0 + (i % nitem)];
+    }
     // ---- activation bits of the slice -> LDS (16 byte-rows = 1 KB per instruction, dealt to the four waves)
-    {
+    const bool have_bits = !REAL || a.amode != K1S_REAL;
+    if (have_bits) {
         const int nrows8 = a.kchunk / 8, last_row = (a.K + 63) / 64 * 8 - 1;
         for (int q = w; q * 16 < nrows8; q += 4) {
             const int br = min((k0 >> 3) + 16 * q + (l >> 2), last_row);
@@ -83,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     // ---- weight ring
     const int colc = min(n0 + 4 * (l & 7), a.N - 4);      // 16-B chunk of the 128-B row segment (N % 4 == 0); clamped chunks feed columns >= N only
     const float* wsrc = a.W + colc;
-    auto issue_slot = [&](int d, int si) {                // ring slot d <- the wave's steps 2 si, 2 si + 1
+    auto issue_slot = [&](int d, int si) __attribute__((always_inline)) {                // ring slot d <- the wave's steps 2 si, 2 si + 1
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int i = 2 * si + sub;
@@ -103,12 +153,68 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     SideLean sl8;
     if (fa.lean) load_side_lean(fa, ecol, mb + 8 * (tid >> 5), sl8);
     else         load_side<8>(fa, ecol, mb + 8 * (tid >> 5), side);
+    // the loop over bf16 terms works one K16 step at a time: weight ring of 6 steps (2 KB each) + A ring of 3 steps (2 NA KB)
+    constexpr int AOPS = 2 * NA;                              // LDS-DMA per A step (2 row halves x NA terms, 1 KB each)
+    const int nkb = (a.K + 15) / 16;
+    const uint32_t aring_lds = ring_lds + K1S_WSTEPS * 2048;
+    const char* aring = ring + K1S_WSTEPS * 2048;
+    const bf16_t* abase = a.arm + (int64_t)mb * 16 + 8 * l;   // lane l: 16 B at [row l >> 1][half l & 1] of a 32-row half
+    auto issue_w = [&](int i) __attribute__((always_inline)) {       // weight step i -> ring position i % 6
+        if (i < my_steps) {                                    // wave-uniform
+            const int krow = k0 + 16 * (4 * i + w) + (l >> 3);
 #pragma unroll
-    for (int d = 0; d < K1S_D; ++d) issue_slot(d, d);
-    // the bits (issued first) have landed once at most the ring's instructions are outstanding
-    if (my_steps >= 2 * K1S_D) wait_vmcnt<4 * K1S_D>(); else wait_vmcnt<0>();
+            for (int h = 0; h < 2; ++h)
+                dma16(wsrc + (int64_t)min(krow + 8 * h, a.K - 1) * a.ldw, ring_lds + ((i % K1S_WSTEPS) * 2 + h) * 1024);
+        }
+    };
+    auto issue_a = [&](int i) __attribute__((always_inline)) {       // A step i -> ring position i % 3: [mt][term] KB
+        if constexpr (REAL) {
+            if (i < my_steps) {
+                const int kb = min((k0 >> 4) + 4 * i + w, nkb - 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NA; ++t)
+                        dma16(abase + t * a.arm_ts + ((int64_t)kb * a.Bp + 32 * mt) * 16, aring_lds + (((i % K1S_ASTEPS) * 2 + mt) * NA + t) * 1024);
+            }
+        }
+    };
+    auto start_real = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < K1S_WSTEPS; ++i) issue_w(i);
+#pragma unroll
+        for (int i = 0; i < K1S_ASTEPS; ++i) issue_a(i);
+    };
+    const bool known_real = REAL && a.amode == K1S_REAL;
+    if (known_real) {
+        start_real();
+    } else {
+#pragma unroll
+        for (int d = 0; d < K1S_D; ++d) issue_slot(d, d);
+        // the bits (issued first) have landed once at most the ring's instructions are outstanding
+        if (my_steps >= 2 * K1S_D) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]) : "i"(4 * K1S_D) : "memory");
+        else                       asm volatile("s_waitcnt vmcnt(0)" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]) :: "memory");
+    }
+    if (adaptive) {
+        // item j of the slice needs its bf16 terms when any of its 8 row groups holds a value that is neither 0 nor 1:
+        // lanes 0-31 / 32-63 of wave w hold row groups 2w / 2w + 1 of items 32 q + j
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long m = __ballot(((fl[q] & FLAG_NONBINARY) != 0u && 32 * q + (tid & 31) < wd) ? 1 : 0);
+            if (l == 0) smask[w * 4 + q] = (uint32_t)m | (uint32_t)(m >> 32);
+        }
+    }
     __syncthreads();
     stamp(st, sblk, 1);
+    uint32_t mk0 = 0u, mk1 = 0u, mk2 = 0u, mk3 = 0u;     // bit j of word q: item 32 q + j of the slice is read from its bf16 terms
+    if (adaptive) {
+        mk0 = __builtin_amdgcn_readfirstlane(smask[0] | smask[4] | smask[8] | smask[12]);
+        mk1 = __builtin_amdgcn_readfirstlane(smask[1] | smask[5] | smask[9] | smask[13]);
+        mk2 = __builtin_amdgcn_readfirstlane(smask[2] | smask[6] | smask[10] | smask[14]);
+        mk3 = __builtin_amdgcn_readfirstlane(smask[3] | smask[7] | smask[11] | smask[15]);
+    }
+    const unsigned long long mlo = (unsigned long long)mk0 | ((unsigned long long)mk1 << 32), mhi = (unsigned long long)mk2 | ((unsigned long long)mk3 << 32);
+    const bool real_loop = REAL && (a.amode == K1S_REAL || (mlo | mhi) != 0ull);
 
     f32x16 acc[2];
 #pragma unroll
@@ -116,39 +222,113 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
-    auto compute = [&](int d, int sub, int i) {           // K16 step i of this wave, in ring slot d
-        const char* base = ring + ((d * 2 + sub) * 2) * 1024 + (8 * kg) * 128 + 4 * n;
-        float x[8];
+    if (!real_loop) {
+        auto compute = [&](int d, int sub, int i) __attribute__((always_inline)) {           // K16 step i of this wave, in ring slot d
+            const char* base = ring + ((d * 2 + sub) * 2) * 1024 + (8 * kg) * 128 + 4 * n;
+            float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(base + j * 128);
-        uint4 bf[NW];
-        make_w_frags<NW>(x, bf);
-        const int jstep = 4 * i + w;                      // K16 step inside the slice: bytes 2 jstep, 2 jstep + 1 of a batch row
+            for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(base + j * 128);
+            uint4 bf[NW];
+            make_w_frags<NW>(x, bf);
+            const int jstep = 4 * i + w;                      // K16 step inside the slice: bytes 2 jstep, 2 jstep + 1 of a batch row
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const uint4 af = bits_to_frag(abl[(2 * jstep + kg) * 64 + 32 * mt + n]);
+            for (int mt = 0; mt < 2; ++mt) {
+                const uint4 af = bits_to_frag(abl[(2 * jstep + kg) * 64 + 32 * mt + n]);
 #pragma unroll
-            for (int tw = 0; tw < NW; ++tw)
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af), as_frag(bf[tw]), acc[mt], 0, 0, 0);
-        }
-    };
-    for (int s0 = 0; s0 < n_slots; s0 += K1S_D) {
-#pragma unroll
-        for (int d = 0; d < K1S_D; ++d) {
-            const int si = s0 + d;
-            if (si < n_slots) {                           // wave-uniform
-                // slot si has landed when only the K1S_D - 1 younger slots are outstanding -- if they were all issued in full
-                if (2 * (si + K1S_D - 1) + 1 < my_steps) wait_vmcnt<4 * (K1S_D - 1)>(); else wait_vmcnt<0>();
-                compute(d, 0, 2 * si);
-                if (2 * si + 1 < my_steps) compute(d, 1, 2 * si + 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's fragments are in registers: refill it
-                issue_slot(d, si + K1S_D);
+                for (int tw = 0; tw < NW; ++tw)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af), as_frag(bf[tw]), acc[mt], 0, 0, 0);
             }
+        };
+        for (int s0 = 0; s0 < n_slots; s0 += K1S_D) {
+#pragma unroll
+            for (int d = 0; d < K1S_D; ++d) {
+                const int si = s0 + d;
+                if (si < n_slots) {                           // wave-uniform
+                    // slot si has landed when only the K1S_D - 1 younger slots are outstanding -- if they were all issued in full
+                    if (2 * (si + K1S_D - 1) + 1 < my_steps) wait_vmcnt<4 * (K1S_D - 1)>(); else wait_vmcnt<0>();
+                    compute(d, 0, 2 * si);
+                    if (2 * si + 1 < my_steps) compute(d, 1, 2 * si + 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's fragments are in registers: refill it
+                    issue_slot(d, si + K1S_D);
+                }
+            }
+        }
+    } else if constexpr (REAL) {
+        // ---- operands with bf16 terms, one K16 step at a time.  Issue order: prologue W0..W5, A0..A2; iteration i, after its
+        // MFMAs: A(i+3), W(i+6).  vmcnt retires in order, so before iteration i everything up to A(i) has landed once only the
+        // younger W(i+3) A(i+1) W(i+4) A(i+2) W(i+5) are outstanding.  (ADAPTIVE: the slots issued above for the bit-plane loop
+        // put steps 6, 7 where this loop's A ring is: drain them and start over -- the price of finding real values in a batch
+        // nobody announced.)
+        if (!known_real) {
+            wait_vmcnt<0>();
+            start_real();
+        }
+        for (int i = 0; i < my_steps; ++i) {
+            // counted waits while everything younger was issued in full (W(i+5) exists)
+            if (i + 5 < my_steps) {
+                if (i >= 3) wait_vmcnt<2 * AOPS + 6>(); else if (i == 2) wait_vmcnt<2 * AOPS + 4>(); else if (i == 1) wait_vmcnt<2 * AOPS + 2>(); else wait_vmcnt<2 * AOPS>();
+            } else wait_vmcnt<0>();
+            const char* base = ring + ((i % K1S_WSTEPS) * 2) * 1024 + (8 * kg) * 128 + 4 * n;
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(base + j * 128);
+            uint4 bf[NW];
+            make_w_frags<NW>(x, bf);
+            const int jstep = 4 * i + w, item = jstep >> 2;
+            const unsigned long long mword = item < 64 ? mlo : mhi;
+            const bool isbin = a.amode == K1S_ADAPTIVE && ((mword >> (item & 63)) & 1ull) == 0ull;      // wave-uniform
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                uint4 at[NA];
+                if (isbin) {
+                    at[0] = bits_to_frag(abl[(2 * jstep + kg) * 64 + 32 * mt + n]);
+#pragma unroll
+                    for (int t = 1; t < NA; ++t) at[t] = make_uint4(0u, 0u, 0u, 0u);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NA; ++t)
+                        at[t] = *reinterpret_cast<const uint4*>(aring + (((i % K1S_ASTEPS) * 2 + mt) * NA + t) * 1024 + n * 32 + kg * 16);
+                }
+#pragma unroll
+                for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+                    for (int tw = 0; tw < NW; ++tw)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(at[ta]), as_frag(bf[tw]), acc[mt], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the step's fragments are in registers: refill its ring places
+            __builtin_amdgcn_sched_barrier(0);
+            issue_a(i + K1S_ASTEPS);
+            issue_w(i + K1S_WSTEPS);
         }
     }
     wait_vmcnt<0>();
     stamp(st, sblk, 2);
     __syncthreads();                                      // every wave is done with its ring: the area becomes red[4][64][32]
+
+    if constexpr (REAL) {
+        // ---- ADAPTIVE slots: where the update kernel will read three planes (an inexact entry in its span of items), give the
+        // all-0/1 items of the span their planes 1, 2 (zeros).  Nothing to do for batches that are 0/1 throughout or real throughout.
+        auto block_or = [&](int v) __attribute__((always_inline)) {      // (the mask words are free now; no static LDS in this kernel)
+            const bool wany = __any(v) != 0;                  // (all lanes: not inside the lane-0 branch)
+            if (l == 0) smask[w] = wany ? 1u : 0u;
+            __syncthreads();
+            const uint32_t r = smask[0] | smask[1] | smask[2] | smask[3];
+            __syncthreads();
+            return r != 0u;
+        };
+        if (fixer && block_or(fixbits & FLAG_INEXACT)) {
+            const int i0 = fix_r * a.fix_span, nitem = min(a.fix_span, a.ncb - i0);
+            for (int it = 0; it < nitem; ++it)
+                for (int zc = 0; zc < a.Bp / 64; ++zc) {
+                    const int nb = (tid < 8) ? (a.aflag[(zc * 8 + tid) * a.ncb + i0 + it] & FLAG_NONBINARY) : 0;
+                    if (block_or(nb)) continue;
+                    for (int i = tid; i < 2 * 64 * 8; i += 256) {
+                        const int pl = 1 + (i >> 9), c = (i >> 3) & 63, q = i & 7, col = (i0 + it) * 64 + c;
+                        if (col < a.K) *reinterpret_cast<uint4*>(a.fix_tr + pl * a.fix_ts + (int64_t)col * a.Bp + zc * 64 + 8 * q) = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+        }
+    }
 
     // ---- cross-wave sum (fixed order) -> this thread's 8 values: column n0 + c, batch rows mb + 8 oct .. + 7
     float* red = reinterpret_cast<float*>(smem);
@@ -166,9 +346,8 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     }
     // caller data that were promised to be 0/1 and are not: the bit plane does not describe them -> NaN, loudly
     int* s_words = reinterpret_cast<int*>(smem + 2 * K1S_RING);        // scratch words behind red[] (the rings are free now)
-    if (a.aflag) {
+    if (!REAL && a.aflag) {
         int bad = 0;
-        const int cb0 = k0 / 64, cb1 = min((k_end + 63) / 64, a.ncb), wd = cb1 - cb0;
         for (int i = tid; i < wd * 8; i += 256) bad |= a.aflag[(z * 8 + i / wd) * a.ncb + cb0 + (i % wd)] & FLAG_NONBINARY;
         if (l == 0) s_words[4 + w] = 0;
         if (__any(bad) && l == 0) s_words[4 + w] = 1;

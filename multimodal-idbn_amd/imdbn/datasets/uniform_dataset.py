@@ -123,7 +123,7 @@ class DeviceLoader:
         self._gen.manual_seed(int(seed))
         self.epoch = 0
         # binary stimuli (every pixel 0 or 255): the batches carry the tag the engine reads instead of checking each one
-        # (HipEngine.data_is_binary): their CD updates read the images as bit planes
+        # (HipEngine.binary_hint): their CD updates read the images as bit planes
         self._binary = bool(((self._x == 0) | (self._x == 255)).all().item()) if self._x.numel() else False
 
     def _global(self) -> int:

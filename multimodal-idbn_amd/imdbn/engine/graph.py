@@ -8,7 +8,7 @@ of one batch -- can be recorded once and replayed with one graph launch instead 
   the number of draw tensors the sequence consumes (``imdbn_rng.dev_offset`` / ``imdbn_rng_advance``), so replay k draws exactly
   what the k-th eager call would have drawn -- results are bit-identical to the eager sequence;
 * **the batch**: the captured calls read STATIC input tensors; copy each new batch into them (``x_static.copy_(batch)``) before
-  ``replay``.  Tag a static 0/1 input once (``x_static._imdbn_binary = True``): a capture cannot run the device check;
+  ``replay`` (what a batch contains is found out on the device, so nothing about it has to be declared);
 * **learning rate / momentum** are host scalars of the epoch: capture once per epoch (``CapturedSteps.epoch`` is a convenience).
 
 The next-batch prefetch (``next_data=``) names a second tensor by address and is left out of captured sequences.

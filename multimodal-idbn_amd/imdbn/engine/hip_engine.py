@@ -8,7 +8,6 @@ scratch workspaces keyed on (device, V, H, B).
 from __future__ import annotations
 
 import os
-import weakref
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -42,10 +41,6 @@ class HipEngine:
         self._pf: Dict[tuple, tuple] = {}           # workspace key -> (identity of the prefetched batch, slot, tensor)
         self._pf_ok: Dict[tuple, bool] = {}
         self.mode = N.PARITY_F32
-        # "is this batch 0/1?" (imdbn_cd_opts.data_binary): answers cached per live tensor object
-        self._bin: Dict[int, tuple] = {}
-        self._bin_misses = 0
-        self.binary_check = os.environ.get("IMDBN_BINARY_CHECK", "auto")      # "auto" | "never"
         # tuning / A-B aid: IMDBN_OPTS="name=value,..." -> imdbn_set_option (include/imdbn_engine.h)
         for kv in filter(None, os.environ.get("IMDBN_OPTS", "").split(",")):
             k, _, v = kv.partition("=")
@@ -249,13 +244,13 @@ class HipEngine:
         return out
 
     def forward(self, rbm, v, data_binary=None):
-        """forward(v) at T = 1 (imdbn_rbm_forward): a 0/1 batch goes through the streaming K1 as a bit plane."""
+        """forward(v) at T = 1 (imdbn_rbm_forward): the streaming K1 reads 0/1 pieces of the batch as a bit plane."""
         d = self._desc(rbm, False)
         x = _f32c(v, "v")
         B, dev = x.size(0), x.device
         out = torch.empty(B, d.H, device=dev)
         ws = self._workspace(dev, d.V, d.H, B)
-        binary = int(self.data_is_binary(v) if data_binary is None else bool(data_binary))
+        binary = self._hint(v, data_binary)
         N.check(self._lib.imdbn_rbm_forward(C.byref(d), _ptr(x), x.stride(0), B, binary, _ptr(out), out.stride(0), _ptr(ws), ws.numel(),
                                              self._stream(dev)), "imdbn_rbm_forward")
         return out
@@ -317,32 +312,29 @@ class HipEngine:
         o.sample_h, o.sample_v, o.reclamp_negative = int(bool(sample_h)), int(bool(sample_v)), int(bool(reclamp))
         return o
 
-    def data_is_binary(self, x: torch.Tensor) -> bool:
-        """True when every element of the batch `x` is known to be exactly 0 or 1: the positive phase of the CD update then
-        reads it as a bit plane (the device re-checks the claim and turns the update into NaN if it is false).
+    @staticmethod
+    def binary_hint(x: torch.Tensor) -> int:
+        """What the HOST knows about the values of the batch `x` (imdbn_cd_opts.data_binary): ``N.DATA_BINARY`` / ``N.DATA_REAL``
+        when the tensor carries the tag ``_imdbn_binary`` (``imdbn.datasets.DeviceLoader`` batches and sequential
+        ``TensorDataset`` loaders: True; engine outputs -- probabilities -- : False), else ``N.DATA_UNKNOWN``.
 
-        Known = the tensor carries the tag ``_imdbn_binary`` (``imdbn.datasets.DeviceLoader`` batches, engine outputs), or
-        this very tensor object (same storage, same version) was checked before.  An unknown tensor is checked once
-        (one device reduction + host sync); after 64 unknown tensors in a row -- a loader that builds a fresh tensor per
-        step -- the engine stops asking and takes the general path.  ``IMDBN_BINARY_CHECK=never`` disables the check."""
+        Unknown is the normal case (a training loop that builds a fresh tensor per step, idbn.py:199-203) and costs nothing:
+        the device decides per 64-column piece of the batch, from the exactness map its own preparation writes, whether the
+        positive phase reads it as a bit plane or as bf16 terms -- the same numbers either way, so results never depend on what
+        the host knew or on what ran before.  The host never inspects a batch (no reduction, no synchronisation)."""
         tag = getattr(x, "_imdbn_binary", None)
-        if tag is not None:
-            return bool(tag)
-        if self.binary_check == "never" or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
-            return False            # (a capture cannot synchronise: tag the static input tensor instead)
-        key = id(x)
-        hit = self._bin.get(key)
-        if hit is not None and hit[0]() is x and hit[1] == (x.data_ptr(), x._version, tuple(x.shape)):
-            self._bin_misses = 0
-            return hit[2]
-        if self._bin_misses >= 64:
-            return False
-        self._bin_misses += 1
-        val = bool(((x == 0) | (x == 1)).all().item())
-        if len(self._bin) > 1024:
-            self._bin = {k: v for k, v in self._bin.items() if v[0]() is not None}
-        self._bin[key] = (weakref.ref(x), (x.data_ptr(), x._version, tuple(x.shape)), val)
-        return val
+        if tag is None:
+            return N.DATA_UNKNOWN
+        return N.DATA_BINARY if tag else N.DATA_REAL
+
+    @staticmethod
+    def _hint(x: torch.Tensor, given) -> int:
+        """`given`: None (ask the tensor's tag), a bool (True: asserted 0/1; False: nothing known) or an N.DATA_* code."""
+        if given is None:
+            return HipEngine.binary_hint(x)
+        if isinstance(given, bool):
+            return N.DATA_BINARY if given else N.DATA_UNKNOWN
+        return int(given)
 
     @staticmethod
     def _ident(t: torch.Tensor):
@@ -370,7 +362,7 @@ class HipEngine:
                 and tuple(next_data.shape) == tuple(x.shape) and next_data.stride(1) == 1 and self.prefetch_ok(d, B)):
             nxt = next_data
             o.next_data, o.ld_next, o.next_slot = nxt.data_ptr(), nxt.stride(0), (2 if o.data_slot == 1 else 1)
-            o.next_binary = int(self.data_is_binary(next_data))
+            o.next_binary = self.binary_hint(next_data)
         return key, nxt
 
     def cd_step(self, rbm, data, lr, mom, cd_k, rng, next_data=None, data_binary=None, forward=False):
@@ -382,7 +374,7 @@ class HipEngine:
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
         o = self._opts(rbm, lr, mom, cd_k, sparsity=getattr(rbm, "sparsity", False))
-        o.data_binary = int(self.data_is_binary(data) if data_binary is None else bool(data_binary))
+        o.data_binary = self._hint(data, data_binary)
         sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
         r, keep = self._rng(rng, sched, B, dev)
         loss = torch.empty(1, device=dev)
@@ -455,7 +447,7 @@ class HipEngine:
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
         o = self._opts(rbm, 0.0, 0.0, cd_k)
-        o.data_binary = int(self.data_is_binary(data) if data_binary is None else bool(data_binary))
+        o.data_binary = self._hint(data, data_binary)
         sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
         r, keep = self._rng(rng, sched, B, dev)
         n = self.packed_floats(d.V, d.H)
@@ -485,7 +477,7 @@ class HipEngine:
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
         o = self._opts(rbm, 0.0, 0.0, cd_k)
-        o.data_binary = int(self.data_is_binary(data) if data_binary is None else bool(data_binary))
+        o.data_binary = self._hint(data, data_binary)
         sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
         r, keep = self._rng(rng, sched, B, dev)
         ws = self._workspace(dev, d.V, d.H, B)
@@ -502,7 +494,7 @@ class HipEngine:
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
         o = self._opts(rbm, 0.0, 0.0, cd_k)
-        o.data_binary = int(self.data_is_binary(data) if data_binary is None else bool(data_binary))
+        o.data_binary = self._hint(data, data_binary)
         sched = R.sched_cd(d.V, d.H, self._groups(rbm), cd_k)
         r, keep = self._rng(rng, sched, B, dev)
         ws = self._workspace(dev, d.V, d.H, B)

@@ -13,6 +13,7 @@ MAX_GROUPS = 4
 ABI_VERSION = 3
 PARITY_F32, FAST_BF16 = 0, 1
 RNG_PHILOX, RNG_REPLAY = 0, 1
+DATA_UNKNOWN, DATA_BINARY, DATA_REAL = 0, 1, 2      # imdbn_cd_opts.data_binary / next_binary (IMDBN_DATA_*)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libimdbn_hip.so"))

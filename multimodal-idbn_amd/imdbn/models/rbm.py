@@ -122,12 +122,12 @@ class RBM(nn.Module):
     def forward(self, v: torch.Tensor, T: float = 1.0) -> torch.Tensor:
         """p(h|v) = sigmoid((v W + c)/max(1e-6,T))   (rbm.py:92)."""
         eng = self._eng()
-        if T == 1.0 and hasattr(eng, "forward") and hasattr(eng, "data_is_binary"):
+        if T == 1.0 and hasattr(eng, "forward") and hasattr(eng, "binary_hint"):
             # the same path as the forward fused into train_epoch(return_forward=True): bit-identical results
-            out = eng.forward(self, self._in(v), data_binary=eng.data_is_binary(v))
+            out = eng.forward(self, self._in(v), data_binary=eng.binary_hint(v))
         else:
             out = eng.prop_up(self, self._in(v), T=T)
-        out._imdbn_binary = False      # probabilities: the next layer's update need not ask (HipEngine.data_is_binary)
+        out._imdbn_binary = False      # probabilities: the next layer's update makes no bit plane of them (HipEngine.binary_hint)
         return out
 
     @torch.no_grad()
@@ -202,9 +202,10 @@ class RBM(nn.Module):
         lr, mom = self._lr_mom(epoch)
         eng, x = self._eng(), self._in(data)
         rng = self._rng(x.size(0))
-        # 0/1 batches (binary images) are read as bit planes by the positive phase; asked of the caller's tensor object,
-        # which may carry the loader's tag (``_in`` makes a fresh view every call)
-        kw = {"data_binary": eng.data_is_binary(data)} if hasattr(eng, "data_is_binary") else {}
+        # 0/1 batches (binary images) are read as bit planes by the positive phase; what a batch contains is found out on the
+        # device (imdbn_cd_opts.data_binary = unknown) unless the caller's tensor object carries a loader's tag (``_in`` makes a
+        # fresh view every call)
+        kw = {"data_binary": eng.binary_hint(data)} if hasattr(eng, "binary_hint") else {}
         dp = _E.dp
         if dp.active():
             B = x.size(0)

@@ -28,7 +28,7 @@ _BIN_ALL: dict = {}       # id(dataset tensor) -> (weakref, (data_ptr, version),
 
 def _all_binary(t: torch.Tensor):
     """Is every element of the (whole, in-memory) dataset tensor exactly 0 or 1?  Asked once per tensor state; None for
-    non-float tensors.  The engine reads 0/1 batches as bit planes (HipEngine.data_is_binary)."""
+    non-float tensors.  The engine reads 0/1 batches as bit planes (HipEngine.binary_hint)."""
     import weakref
     if not t.is_floating_point() or t.numel() == 0:
         return None

@@ -41,14 +41,12 @@ def test_captured_train_epoch_replays_equal_eager_calls(V, H, B, binary):
     g = np.random.default_rng(V)
     mk = (lambda: (g.random((B, V), dtype=F32) > 0.7).astype(F32)) if binary else (lambda: g.random((B, V), dtype=F32))
     Xs = [P.T(mk(), DEV) for _ in range(7)]
-    for x in Xs:
-        x._imdbn_binary = binary        # both runs must take the same kernel path (an untagged tensor is checked -- or, after 64 unknown
-                                        # tensors in a row, no longer asked about and sent down the general path)
+    # (untagged tensors: what a batch contains is found out on the device, per 64-column piece, with the same numbers whichever
+    #  way a piece is read -- nothing about the inputs has to be declared, and nothing depends on what ran before)
     ra, rb = _rbm(V, H, 3), _rbm(V, H, 3)
     with E.use_rng(E.PhiloxRng(seed=12)):
         la = [float(ra.train_epoch(x, 2, 10, CD=1)) for x in Xs]
     x_static = Xs[0].clone()
-    x_static._imdbn_binary = binary
     with E.use_rng(E.PhiloxRng(seed=12)) as _:
         step = E.CapturedSteps(lambda: rb.train_epoch(x_static, 2, 10, CD=1))
         lb = []
@@ -70,8 +68,6 @@ def test_captured_layer_loop_and_clamped_update_equal_eager_calls():
     B = 32
     g = np.random.default_rng(5)
     Xs = [P.T((g.random((B, 400), dtype=F32) > 0.8).astype(F32), DEV) for _ in range(5)]
-    for x in Xs:
-        x._imdbn_binary = True
     Ys = [P.T(np.eye(8, dtype=F32)[g.integers(0, 8, B)], DEV) for _ in range(5)]
 
     def build():
@@ -92,7 +88,6 @@ def test_captured_layer_loop_and_clamped_update_equal_eager_calls():
         la = [batch(*a, x, y).cpu() for x, y in zip(Xs, Ys)]
     b = build()
     xs, ys = Xs[0].clone(), Ys[0].clone()
-    xs._imdbn_binary = True
     with E.use_rng(E.PhiloxRng(seed=4)):
         step = E.CapturedSteps(lambda: batch(*b, xs, ys))
         lb = []

@@ -72,13 +72,47 @@ def test_k3_counted_waits_match_the_emitted_prefetch_loads(functions):
     assert len(updating) >= 4 and checked >= 2 * len(updating)          # prologue + tile loop of each
 
 
+def _check_term_loop_counts(name, body, na):
+    """k1_stream's loop over bf16 terms (kernels_stream.hpp): per K16 step 2 LDS-DMA of weights and 2 NA LDS-DMA of A fragments, issued
+    after the step's MFMAs as A(i+3), W(i+6); its counted wait leaves the younger W(i+3) A(i+1) W(i+4) A(i+2) W(i+5) in flight =
+    4 NA + 6 operations.  Checked in the emitted code: between two consecutive counted waits of the steady state lie exactly 2 NA + 2
+    LDS-DMA (one step's worth), and no register-destination load at all (the compiler would wait vmcnt(0) for it)."""
+    steady = 4 * na + 6
+    in_asm, seen, dma, plain, counting = False, 0, 0, 0, False
+    for l in body:
+        if l.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if l.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if "global_load_lds_dwordx4" in l:
+            dma += 1
+        elif re.match(r"(global|buffer|flat)_load_", l):
+            plain += 1
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", l) if in_asm else None
+        if m:
+            if counting:      # the step that started with the steady-state wait: its refills up to the next hand-written vmcnt wait
+                assert dma == 2 * na + 2 and plain == 0, f"{name}: {dma} LDS-DMA / {plain} register loads per step, the waits assume {2 * na + 2} / 0"
+                seen += 1
+            counting = int(m.group(1)) == steady
+            dma = plain = 0
+    assert seen >= 1, f"{name}: no steady-state step (vmcnt({steady})) found"
+
+
 def test_streaming_kernels_have_no_scratch_and_only_the_planned_counts(functions):
     ks = {k: v for k, v in functions.items() if "k1_streamILi" in k}
-    assert ks
+    assert len(ks) >= 5
     for name, body in ks.items():
+        na = int(re.search(r"k1_streamILi\dELi(\d)E", name).group(1))      # bf16 terms the kernel can read per element (0: bit planes only)
         counts = {n for _, n in _hand_waits(body)}
-        assert counts <= {0, 12, 16}, (name, counts)      # 0, 4 (D - 1), 4 D  (kernels_stream.hpp K1S_D = 4)
+        planned = {0, 12, 16}                                 # 0, 4 (D - 1), 4 D  (kernels_stream.hpp K1S_D = 4): the bit-plane loop
+        if na:
+            planned |= {4 * na, 4 * na + 2, 4 * na + 4, 4 * na + 6}       # loop over bf16 terms: A(i+1) A(i+2) [+ W(i+3)] [+ W(i+4)] [+ W(i+5)] may stay in flight
+        assert counts <= planned, (name, counts)
         assert not any(l.startswith("scratch_") for l in body), f"{name} spills to scratch"
+        if na:
+            _check_term_loop_counts(name, body, na)
     for name, body in functions.items():
         if "k2_streamILi" in name:
             assert not any(l.startswith("scratch_") for l in body), f"{name} spills to scratch"

@@ -787,8 +787,7 @@ def test_idbn_train_lookahead_with_a_ragged_last_batch_equals_plain_loop(tmp_pat
         with E.use_rng(E.PhiloxRng(seed=6)):                       # the same loop without any hint
             for epoch in range(2):
                 for s in range(0, 164, 64):
-                    v = X[s:s + 64]
-                    v._imdbn_binary = True          # (what iDBN.train learns about the dataset tensor once: same kernel path in both runs)
+                    v = X[s:s + 64]                 # untagged: the device finds out what the batch contains; same numbers either way
                     for rbm in b.layers:
                         rbm.train_epoch(v, epoch, 2, CD=1)
                         v = rbm.forward(v)

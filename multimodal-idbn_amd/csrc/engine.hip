@@ -49,6 +49,8 @@ struct Tuning {
     int k2s_tr = 0;                  // tuning: rows per k2_stream block (0 = automatic; multiple of 8, <= 48)
     int no_k1s_real = 0;             // testing: real-valued operands of K1 take the partial GEMM + finish launches, not k1_stream
     int no_adaptive = 0;             // testing: a prefetched batch of unknown content gets all three-term forms (no per-item choice)
+    int k1s_lds_pad = 0;             // experiment: extra dynamic LDS (bytes) for the bit-plane k1_stream
+    int k1s_force_na = 0;            // experiment: bit-plane operands run on the kernel instantiation that can also read bf16 terms
 };
 Tuning g_defaults;
 thread_local const Tuning* t_bound = nullptr;
@@ -72,6 +74,8 @@ inline const Tuning& tune() { return t_bound ? *t_bound : g_defaults; }
 #define g_k2s_tr (tune().k2s_tr)
 #define g_no_k1s_real (tune().no_k1s_real)
 #define g_no_adaptive (tune().no_adaptive)
+#define g_k1s_lds_pad (tune().k1s_lds_pad)
+#define g_k1s_force_na (tune().k1s_force_na)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
@@ -309,6 +313,7 @@ struct Ctx {
     bool hid_bits_ok = false;      // L.hid_bits describes the current contents of L.hid_rm
     bool data_prepped = false;     // cd_phases: the data-side operands are already in place (prefetch slot)
     int down_blocks = 0;           // blocks (per batch chunk) of the last K2 launch: the number of squared-error partials it left
+    bool pos_phase = false;        // tuning aid: the propagation being launched is the positive phase of a CD pass (dbg bit 2048 stamps it, bit 64 the others)
     bool fix_slot = false;         // the data-side operands were written item by item (PrepArgs::adaptive): the next k1_stream that reads them
                                    // completes the planes of mixed spans for the update kernel (K1sArgs::fix_tr)
     Ctx(const imdbn_rbm_desc* d_, imdbn_rng* r, hipStream_t s_) : d(d_), s(s_), rng(r) {
@@ -369,6 +374,12 @@ struct OpIn { const bf16_t* rm; int terms; const int* flag; const uint8_t* bits 
 int k3_tiles_per_block(int V, int H) {
     const int nh = cdiv(H, 128), nv = cdiv(V, 128);
     return std::max(1, cdiv(nh * nv, std::max(cu_count(), 1)));
+}
+// The per-item choice of k1_stream (K1S_ADAPTIVE) holds one exactness-map entry per thread for a K slice's items (<= 32) and one
+// for a span of the update kernel (<= 256 entries); layers outside that read data of unknown content from the bf16 terms throughout
+// (same numbers, all three-term forms prepared).
+bool adaptive_shape_ok(const Layout& L) {
+    return L.k1s_kchunk <= 2048 && 2 * k3_tiles_per_block(L.V, L.H) * L.P <= 256;
 }
 
 bool vec4_weights(const imdbn_rbm_desc* d) {
@@ -439,7 +450,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         a.abits = in.bits; a.Bp = L.Bp;
         a.aflag = in.binary >= 2 ? in.flag : nullptr; a.ncb = cdiv(L.Vpad, 64); a.P = L.P;
         a.slabs = L.partial; a.counters = L.k1s_cnt; a.kchunk = L.k1s_kchunk; a.ks = L.k1s_ks;
-        a.amode = k1s_bits ? (in.binary == 2 ? K1S_ASSERTED : K1S_BITS) : (in.binary == 3 ? K1S_ADAPTIVE : K1S_REAL);
+        a.amode = k1s_bits ? (in.binary == 2 ? K1S_ASSERTED : K1S_BITS) : ((in.binary == 3 && adaptive_shape_ok(L)) ? K1S_ADAPTIVE : K1S_REAL);
         a.arm = in.rm; a.arm_ts = (int64_t)L.Bp * L.Vpad;
         if (a.amode == K1S_ADAPTIVE && c.fix_slot && in.rm == L.vis_rm[0]) {
             const int tpb = k3_tiles_per_block(L.V, L.H);
@@ -448,39 +459,36 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
             c.fix_slot = false;
         }
         // terms the kernel multiplies per element: the operand form carries `in.terms` of them (0 = prep's three, nw in FAST mode)
-        const int na = k1s_bits ? 0 : ((in.terms == 1 || c.nw == 1) ? 1 : 3);
-        f.dbg = g_dbg;
+        const int na = k1s_bits ? ((g_k1s_force_na && !next) ? c.nw : 0) : ((in.terms == 1 || c.nw == 1) ? 1 : 3);
+        f.dbg = c.pos_phase ? ((g_dbg & 2048) ? 64 : 0) : (g_dbg & ~2048);
         f.op.bits = want_hbits ? L.hid_bits : nullptr; f.op.bits_shape = 1; f.op.bits_cols = 32;
         if (f.op.rm == L.hid_rm) c.hid_bits_ok = want_hbits;
         if (want_hbits && !g_no_bits) f.op.rm = nullptr, f.rm_src = 0;      // the fused K2 reads the bit plane, nobody reads the bf16 form
         // 80 KB at the headline shape: two workgroups per CU (the bit-plane kernel carries the next batch's preparation blocks)
-        const size_t lds = na > 0 ? (size_t)4 * K1S_REGION_REAL + (size_t)8 * a.kchunk + K1S_LDS_EXTRA : (size_t)4 * K1S_RING + (size_t)8 * a.kchunk;
-        static bool attr_done = false;
-        if (!attr_done) {
-            const int mx = 4 * K1S_REGION_REAL + 8 * K1S_MAX_KCHUNK + K1S_LDS_EXTRA;
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-            HIPCHK(hipFuncSetAttribute((const void*)k1_stream<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-            attr_done = true;
-        }
+        a.region = k1s_bits ? K1S_RING : K1S_REGION_REAL;
+        const size_t lds = (size_t)4 * a.region + (size_t)8 * a.kchunk + (k1s_bits ? (next ? 0 : g_k1s_lds_pad) : K1S_LDS_EXTRA);
         f.lean = lean_ok(f);
         // + block rows that prepare the next batch (one 64-column item each, or a few)
         PrepArgs pz;
         memset(&pz, 0, sizeof(pz));
         const int items = next ? cdiv(std::max(next->N, next->op.ldrm), 64) : 0;
         const int pr = next ? std::min(8, cdiv(items, L.k1s_tiles)) : 0;
+        if (pr > 0 && na != 0) return fail(IMDBN_E_INVALID, "internal: preparation blocks ride on the bit-plane k1_stream only");
         dim3 grid(L.k1s_tiles, a.ks + pr, mb);
         const PrepArgs& pa = next ? *next : pz;
-        if (c.nw == 3) {
-            if (na == 0)      hipLaunchKernelGGL((k1_stream<3, 0>), grid, dim3(256), lds, c.s, a, f, pa);
-            else if (na == 1) hipLaunchKernelGGL((k1_stream<3, 1>), grid, dim3(256), lds, c.s, a, f, pa);
-            else              hipLaunchKernelGGL((k1_stream<3, 3>), grid, dim3(256), lds, c.s, a, f, pa);
-        } else {
-            if (na == 0)      hipLaunchKernelGGL((k1_stream<1, 0>), grid, dim3(256), lds, c.s, a, f, pa);
-            else              hipLaunchKernelGGL((k1_stream<1, 1>), grid, dim3(256), lds, c.s, a, f, pa);
-        }
+        hipError_t le = hipSuccess;
+#define LAUNCH_K1S(NWV, NAV, GEV, RV) do { \
+        static bool attr = false; \
+        if (!attr) { le = hipFuncSetAttribute((const void*)k1_stream<NWV, NAV, GEV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_REGION_REAL + 8 * K1S_MAX_KCHUNK + K1S_LDS_EXTRA); attr = true; } \
+        if (le == hipSuccess) hipLaunchKernelGGL((k1_stream<NWV, NAV, GEV, RV>), grid, dim3(256), lds, c.s, a, f, pa); } while (0)
+#define LAUNCH_K1S_G(NWV, NAV, RV) do { if (f.lean) LAUNCH_K1S(NWV, NAV, false, RV); else LAUNCH_K1S(NWV, NAV, true, RV); } while (0)
+        // (one instantiation per case: code that a launch does not run -- the general epilogue, the preparation blocks, the loop over
+        //  bf16 terms -- still costs it time)
+        if (c.nw == 3) { if (na == 0) { if (pr > 0) LAUNCH_K1S_G(3, 0, true); else LAUNCH_K1S_G(3, 0, false); } else if (na == 1) LAUNCH_K1S_G(3, 1, false); else LAUNCH_K1S_G(3, 3, false); }
+        else           { if (na == 0) { if (pr > 0) LAUNCH_K1S_G(1, 0, true); else LAUNCH_K1S_G(1, 0, false); } else LAUNCH_K1S_G(1, 1, false); }
+#undef LAUNCH_K1S_G
+#undef LAUNCH_K1S
+        HIPCHK(le);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -719,7 +727,10 @@ int cd_phases(Ctx& c, const float* data, int64_t ldd, const imdbn_cd_opts* o, co
         f.op.rm = L.hid_rm; f.op.rm_terms = 1; f.rm_src = 2;
         f.op.tr = L.hid_tr[0]; f.op.tr_terms = c.ht; f.tr_src = 1;
         f.colsum_part = L.cs_hpos; f.colsum_src = 1;
-        CHK(prop(c, true, OpIn{L.vis_rm[0], c.nw == 1 ? 1 : 0, L.flags, L.vis_bits[0], data_operand_kind(o->data_binary)}, f));
+        c.pos_phase = true;
+        const int rc = prop(c, true, OpIn{L.vis_rm[0], c.nw == 1 ? 1 : 0, L.flags, L.vis_bits[0], data_operand_kind(o->data_binary)}, f);
+        c.pos_phase = false;
+        CHK(rc);
     }
     for (int it = 0; it < o->cd_k; ++it) {
         const bool last = (it == o->cd_k - 1);
@@ -953,6 +964,8 @@ static int set_opt(Tuning& t, const char* name, int value) {
     else if (!strcmp(name, "generic_k1")) t.no_fast_k1 = value != 0;
     else if (!strcmp(name, "no_k1s_real")) t.no_k1s_real = value;
     else if (!strcmp(name, "no_adaptive")) t.no_adaptive = value;
+    else if (!strcmp(name, "k1s_force_na")) t.k1s_force_na = value;
+    else if (!strcmp(name, "k1s_lds_pad")) t.k1s_lds_pad = std::max(0, std::min(value, 64 * 1024));
     else if (!strcmp(name, "no_fused_up")) t.no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);
     return 0;
@@ -1168,7 +1181,7 @@ static int cd_prologue(Ctx& c, const imdbn_cd_opts* o, PrepArgs& pn, bool& rides
         if (o->next_binary == IMDBN_DATA_BINARY) {
             // a 0/1 batch: the positive phase reads the bit plane, the update kernel one bf16 plane (the exactness map says "one term")
             pn.op.rm = nullptr; pn.op.rm_terms = 0; pn.op.tr_terms = 1;
-        } else if (o->next_binary == IMDBN_DATA_UNKNOWN && rides && !g_no_adaptive && !g_no_k1s_real) {
+        } else if (o->next_binary == IMDBN_DATA_UNKNOWN && rides && !g_no_adaptive && !g_no_k1s_real && adaptive_shape_ok(c.L)) {
             pn.adaptive = 1;      // the same slim set for every 64-column item that turns out to be all 0/1, decided by the preparing block
         }
     }

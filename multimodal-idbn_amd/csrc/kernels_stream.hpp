@@ -24,14 +24,20 @@ __device__ __forceinline__ void dma16(const void* g, uint32_t lds_off) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");      // wave-uniform by construction
 }
+// the same with 4 B per lane: lane i's dword lands at LDS[lds_off + 4 i]
+__device__ __forceinline__ void dma4(const void* g, uint32_t lds_off) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
 constexpr int K1S_D = 4;                          // ring slots per wave; a slot = 2 K16 steps = 4 instructions = 32 rows x 128 B
 constexpr int K1S_RING = K1S_D * 4 * 1024;        // 16 KB per wave
 constexpr int K1S_REGION_REAL = 32 * 1024;        // per-wave LDS of the kernels that can read bf16 terms: weight ring (6 K16 steps, 12 KB) + A ring (3 steps x 2 NA KB)
 constexpr int K1S_WSTEPS = 6, K1S_ASTEPS = 3;     // ring depths (K16 steps) of that loop
-constexpr int K1S_MAX_KCHUNK = 3840;              // LDS: rings + 8 B per K row of activation bits (4 x 32 KB + 30 KB + mask words < 160 KB)
-constexpr int K1S_LDS_EXTRA = 64;                 // item-mask words behind the bits (adaptive operands)
+constexpr int K1S_MAX_KCHUNK = 3584;              // LDS: rings + 8 B per K row of activation bits (4 x 32 KB + 28 KB + K1S_LDS_EXTRA <= 160 KB)
+constexpr int K1S_LDS_EXTRA = 64 + 2048;          // behind the bits (adaptive operands): 16 mask / scratch words, 2 x 256 exactness-map entries
 
 // How the activation operand of k1_stream is read (K1sArgs::amode).  Whatever the mode, a K16 step multiplies the same
 // fragments in the same order -- for a 0/1 value the bit plane and the first bf16 term are the same number and the further
@@ -50,11 +56,13 @@ struct K1sArgs {
     int* counters;                                // [Bp/64][tiles] arrival counters, zero at launch, zero again at exit
     int kchunk, ks;                               // rows per K slice (multiple of 64), number of slices
     int amode;                                    // K1S_*
+    int region;                                   // LDS bytes per wave: K1S_RING, or K1S_REGION_REAL where the loop over bf16 terms may run
     const bf16_t* arm; int64_t arm_ts;            // K16-blocked operand form [term][ceil(K/16)][Bp][16] (ADAPTIVE: valid for non-binary items)
     // ADAPTIVE operands written item by item (prep_item_process, PrepArgs::adaptive): an all-0/1 item has ONE transposed plane, but
     // the update kernel decides 1 or 3 planes per block over `fix_span` items -- where a span mixes both kinds, the binary items'
     // planes 1, 2 are zeroed here (what a three-term split of 0/1 values is).  Cold path; nullptr = off.
     bf16_t* fix_tr; int64_t fix_ts; int fix_span, fix_ranges;
+
 };
 
 // `next` / block rows >= a.ks: the launch can carry the preparation of the NEXT batch of the training loop (prep_item_body:
@@ -68,11 +76,16 @@ struct K1sArgs {
 // by LDS-DMA into a second per-wave ring beside the weight ring -- no registers, every wait hand-counted (register loads written
 // in inline asm were tried: the compiler moves their destination registers around before the wait that makes them valid; plain
 // loads make it wait vmcnt(0) at every use beside LDS-DMA).  A block whose K slice holds only 0/1 items runs the bit-plane loop.
-template <int NW, int NA>
+// GE = the general epilogue (temperature, noise, clamp, fp32 outputs, K16-blocked form ...) is compiled in; the launches of a
+// CD pass only need the lean one (FinishArgs::lean), and a kernel without the general epilogue's ~25 000 instructions (and, for
+// NA > 0, without the preparation blocks) measurably starts and runs faster: code size is not free here.
+// RIDER = the launch may carry preparation blocks of the next batch (bit-plane instantiation only).
+template <int NW, int NA, bool GE, bool RIDER>
 __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const FinishArgs fa, const PrepArgs next) {
     constexpr bool REAL = NA > 0;
+    static_assert(!(RIDER && REAL), "preparation blocks ride on the bit-plane instantiation");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 rings][activation bits][mask words]; no static LDS (keeps the base 16-B aligned)
-    if ((int)blockIdx.y >= a.ks) {
+    if (RIDER && (int)blockIdx.y >= a.ks) {
         const int nworkers = (gridDim.y - a.ks) * gridDim.x, wid = (blockIdx.y - a.ks) * gridDim.x + blockIdx.x;
         const int ntx = (max(next.N, next.op.ldrm) + 63) / 64;
         for (int it = wid; it < ntx; it += nworkers) {
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     const int nsteps = (k_end - k0) / 16;                 // K16 steps of this slice; wave w takes steps w, w + 4, ...
     const int my_steps = (nsteps - w + 3) / 4;
     const int n_slots = (my_steps + 1) / 2;
-    constexpr int REGION = REAL ? K1S_REGION_REAL : K1S_RING;      // LDS per wave
+    const int REGION = a.region;                          // LDS per wave
     char* ring = smem + w * REGION;
     const uint8_t* abl = reinterpret_cast<const uint8_t*>(smem + 4 * REGION);      // [kchunk/8][64] bytes
     uint32_t* smask = reinterpret_cast<uint32_t*>(smem + 4 * REGION + 8 * a.kchunk);      // [4 waves][4 words]
@@ -100,27 +113,18 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     const int sblk = (z * gridDim.y + sl) * ntiles + tile;
     stamp(st, sblk, 0);
     const int cb0 = k0 / 64, cb1 = min((k_end + 63) / 64, a.ncb), wd = cb1 - cb0;      // 64-column items of this slice
-    // ---- ADAPTIVE: the exactness-map entries of the slice's items, requested first (oldest in the in-order vmcnt queue: they
-    // have landed when the bits have).  Thread (p = tid >> 5, j = tid & 31) holds row group p of items j, 32 + j, ...; hand-written
-    // loads: the compiler's own wait for them would also cover part of the weight ring issued below.
-    uint32_t fl[4] = {0u, 0u, 0u, 0u};
+    // ---- ADAPTIVE (host: at most 32 items per slice, at most 256 map entries per span of the update kernel): thread (p = tid >> 5,
+    // j = tid & 31) fetches the exactness-map entry of row group p of item j, and entry `tid` of the span the update kernel ORs for
+    // one of its blocks.  The two loads are requested BEHIND the bits and the first ring slots and looked at after the bit-plane
+    // loop: a batch of 0/1 images -- the case that matters -- runs exactly the instruction stream of the bit-plane kernel, and a
+    // slice that turns out to hold other values is done again from its bf16 terms.  They are LDS-DMA like everything else in
+    // flight here (no destination registers: register loads written in inline asm were tried -- the compiler copies their
+    // destinations around before the wait that makes them valid -- and its own loads it waits for with vmcnt(0)).
     const bool adaptive = REAL && a.amode == K1S_ADAPTIVE;
-    if (adaptive) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int* fp = a.aflag + (int64_t)(z * 8 + (tid >> 5)) * a.ncb + min(cb0 + 32 * q + (tid & 31), a.ncb - 1);
-            asm volatile("global_load_dword %0, %1, off" : "=&v"(fl[q]) : "v"(fp) : "memory");
-        }
-    }
-    // the entries the update kernel will OR for one of its blocks (fix_span items x all row groups): requested now, looked at
-    // after the K loop
-    int fixbits = 0;
     const int fix_r = sl * ntiles + tile;
     const bool fixer = REAL && adaptive && a.fix_tr && z == 0 && fix_r < a.fix_ranges;
-    if (fixer) {
-        const int i0 = fix_r * a.fix_span, nitem = min(a.fix_span, a.ncb - i0);
-        for (int i = tid; i < nitem * a.P; i += 256) fixbits |= a.aflag[(i / nitem) * a.ncb + i0 + (i % nitem)];
-    }
+    constexpr int NF = 2;                                 // those loads, per wave
+    const uint32_t* sfl = smask + 16;                     // [256] entries of the slice's items, [256] of the span
     // ---- activation bits of the slice -> LDS (16 byte-rows = 1 KB per instruction, dealt to the four waves)
     const bool have_bits = !REAL || a.amode != K1S_REAL;
     if (have_bits) {
@@ -148,11 +152,13 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     // epilogue side inputs (bias, ...) of this thread's column x 8 rows: requested now (before the ring, so that the counted
     // waits below still see the ring's instructions as the youngest), used by the tile's last arriver -- their first-touch
     // latency would otherwise sit behind the split-K combine
-    const int ecol = (n0 + (tid & 31) < a.N) ? n0 + (tid & 31) : (1 << 30);
+    // (the true column also past N: the epilogue stores nothing there but the zeros of the K16-blocked form's padding columns
+    //  [N, ldrm), which the next propagation multiplies with clamped, non-zero weights; 32-column tiles never overlap)
+    const int ecol = n0 + (tid & 31);
     SideIn<8> side;
     SideLean sl8;
-    if (fa.lean) load_side_lean(fa, ecol, mb + 8 * (tid >> 5), sl8);
-    else         load_side<8>(fa, ecol, mb + 8 * (tid >> 5), side);
+    if (!GE || fa.lean) load_side_lean(fa, ecol, mb + 8 * (tid >> 5), sl8);
+    else if constexpr (GE) load_side<8>(fa, ecol, mb + 8 * (tid >> 5), side);
     // the loop over bf16 terms works one K16 step at a time: weight ring of 6 steps (2 KB each) + A ring of 3 steps (2 NA KB)
     constexpr int AOPS = 2 * NA;                              // LDS-DMA per A step (2 row halves x NA terms, 1 KB each)
     const int nkb = (a.K + 15) / 16;
@@ -192,29 +198,19 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
 #pragma unroll
         for (int d = 0; d < K1S_D; ++d) issue_slot(d, d);
         // the bits (issued first) have landed once at most the ring's instructions are outstanding
-        if (my_steps >= 2 * K1S_D) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]) : "i"(4 * K1S_D) : "memory");
-        else                       asm volatile("s_waitcnt vmcnt(0)" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]) :: "memory");
-    }
-    if (adaptive) {
-        // item j of the slice needs its bf16 terms when any of its 8 row groups holds a value that is neither 0 nor 1:
-        // lanes 0-31 / 32-63 of wave w hold row groups 2w / 2w + 1 of items 32 q + j
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned long long m = __ballot(((fl[q] & FLAG_NONBINARY) != 0u && 32 * q + (tid & 31) < wd) ? 1 : 0);
-            if (l == 0) smask[w * 4 + q] = (uint32_t)m | (uint32_t)(m >> 32);
+        if (adaptive) {
+            const int i0 = fixer ? fix_r * a.fix_span : 0, nitem = fixer ? min(a.fix_span, a.ncb - i0) : 1, ne = fixer ? nitem * a.P : 1;
+            const int ie = min(tid, ne - 1);
+            const uint32_t sfl_lds = abl_lds + 8 * a.kchunk + 64 + w * 256;
+            dma4(a.aflag + (int64_t)(z * 8 + (tid >> 5)) * a.ncb + min(cb0 + (tid & 31), a.ncb - 1), sfl_lds);
+            dma4(a.aflag + (int64_t)(ie / nitem) * a.ncb + i0 + (ie % nitem), sfl_lds + 1024);
         }
+        // the bits (issued first) have landed once at most the ring's instructions (and the map loads behind them) are outstanding
+        if (my_steps >= 2 * K1S_D) { if (adaptive) wait_vmcnt<4 * K1S_D + NF>(); else wait_vmcnt<4 * K1S_D>(); }
+        else wait_vmcnt<0>();
     }
     __syncthreads();
     stamp(st, sblk, 1);
-    uint32_t mk0 = 0u, mk1 = 0u, mk2 = 0u, mk3 = 0u;     // bit j of word q: item 32 q + j of the slice is read from its bf16 terms
-    if (adaptive) {
-        mk0 = __builtin_amdgcn_readfirstlane(smask[0] | smask[4] | smask[8] | smask[12]);
-        mk1 = __builtin_amdgcn_readfirstlane(smask[1] | smask[5] | smask[9] | smask[13]);
-        mk2 = __builtin_amdgcn_readfirstlane(smask[2] | smask[6] | smask[10] | smask[14]);
-        mk3 = __builtin_amdgcn_readfirstlane(smask[3] | smask[7] | smask[11] | smask[15]);
-    }
-    const unsigned long long mlo = (unsigned long long)mk0 | ((unsigned long long)mk1 << 32), mhi = (unsigned long long)mk2 | ((unsigned long long)mk3 << 32);
-    const bool real_loop = REAL && (a.amode == K1S_REAL || (mlo | mhi) != 0ull);
 
     f32x16 acc[2];
 #pragma unroll
@@ -222,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
-    if (!real_loop) {
+    if (!known_real) {
         auto compute = [&](int d, int sub, int i) __attribute__((always_inline)) {           // K16 step i of this wave, in ring slot d
             const char* base = ring + ((d * 2 + sub) * 2) * 1024 + (8 * kg) * 128 + 4 * n;
             float x[8];
@@ -245,7 +241,9 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
                 const int si = s0 + d;
                 if (si < n_slots) {                           // wave-uniform
                     // slot si has landed when only the K1S_D - 1 younger slots are outstanding -- if they were all issued in full
-                    if (2 * (si + K1S_D - 1) + 1 < my_steps) wait_vmcnt<4 * (K1S_D - 1)>(); else wait_vmcnt<0>();
+                    // (ADAPTIVE, first pass over the ring: plus the map loads issued behind the first slots)
+                    if (2 * (si + K1S_D - 1) + 1 < my_steps) { if (adaptive && s0 == 0) wait_vmcnt<4 * (K1S_D - 1) + NF>(); else wait_vmcnt<4 * (K1S_D - 1)>(); }
+                    else wait_vmcnt<0>();
                     compute(d, 0, 2 * si);
                     if (2 * si + 1 < my_steps) compute(d, 1, 2 * si + 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's fragments are in registers: refill it
@@ -253,14 +251,37 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
                 }
             }
         }
-    } else if constexpr (REAL) {
+    }
+    uint32_t mlo = 0u;                                    // bit j: item j of the slice is read from its bf16 terms
+    if constexpr (REAL) {
+        if (adaptive) {
+            // item j of the slice needs its bf16 terms when any of its 8 row groups holds a value that is neither 0 nor 1:
+            // lanes 0-31 / 32-63 of wave w hold row groups 2w / 2w + 1 of items 32 q + j
+            wait_vmcnt<0>();
+            const unsigned long long m = __ballot(((sfl[tid] & FLAG_NONBINARY) != 0u && (tid & 31) < wd) ? 1 : 0);
+            if (l == 0) smask[w] = (uint32_t)m | (uint32_t)(m >> 32);
+        }
+    }
+    if (!known_real) wait_vmcnt<0>();                     // (announced real values: the rings requested in the prologue stay in flight)
+    stamp(st, sblk, 2);
+    __syncthreads();                                      // every wave is done with its ring (the area becomes red[4][64][32]); the mask words are complete
+    if constexpr (REAL) {
+        if (adaptive) {
+            mlo = __builtin_amdgcn_readfirstlane(smask[0] | smask[1] | smask[2] | smask[3]);      // items 0 .. 31 of the slice
+        }
+    }
+    const bool real_loop = REAL && (known_real || mlo != 0u);
+    if constexpr (REAL) if (real_loop) {
         // ---- operands with bf16 terms, one K16 step at a time.  Issue order: prologue W0..W5, A0..A2; iteration i, after its
         // MFMAs: A(i+3), W(i+6).  vmcnt retires in order, so before iteration i everything up to A(i) has landed once only the
-        // younger W(i+3) A(i+1) W(i+4) A(i+2) W(i+5) are outstanding.  (ADAPTIVE: the slots issued above for the bit-plane loop
-        // put steps 6, 7 where this loop's A ring is: drain them and start over -- the price of finding real values in a batch
-        // nobody announced.)
+        // younger W(i+3) A(i+1) W(i+4) A(i+2) W(i+5) are outstanding.  (ADAPTIVE: the slice was first run as bit planes -- all waves
+        // are past that loop, the rings are free -- and is done again from scratch: the price of real values in a batch nobody
+        // announced.)
         if (!known_real) {
-            wait_vmcnt<0>();
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
             start_real();
         }
         for (int i = 0; i < my_steps; ++i) {
@@ -275,8 +296,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             uint4 bf[NW];
             make_w_frags<NW>(x, bf);
             const int jstep = 4 * i + w, item = jstep >> 2;
-            const unsigned long long mword = item < 64 ? mlo : mhi;
-            const bool isbin = a.amode == K1S_ADAPTIVE && ((mword >> (item & 63)) & 1ull) == 0ull;      // wave-uniform
+            const bool isbin = a.amode == K1S_ADAPTIVE && ((mlo >> (item & 31)) & 1u) == 0u;      // wave-uniform
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 uint4 at[NA];
@@ -300,10 +320,9 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             issue_a(i + K1S_ASTEPS);
             issue_w(i + K1S_WSTEPS);
         }
+        wait_vmcnt<0>();
+        __syncthreads();                                  // every wave is done with its rings
     }
-    wait_vmcnt<0>();
-    stamp(st, sblk, 2);
-    __syncthreads();                                      // every wave is done with its ring: the area becomes red[4][64][32]
 
     if constexpr (REAL) {
         // ---- ADAPTIVE slots: where the update kernel will read three planes (an inexact entry in its span of items), give the
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             __syncthreads();
             return r != 0u;
         };
-        if (fixer && block_or(fixbits & FLAG_INEXACT)) {
+        if (fixer && block_or(sfl[256 + tid] & FLAG_INEXACT)) {
             const int i0 = fix_r * a.fix_span, nitem = min(a.fix_span, a.ncb - i0);
             for (int it = 0; it < nitem; ++it)
                 for (int zc = 0; zc < a.Bp / 64; ++zc) {
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     }
     // caller data that were promised to be 0/1 and are not: the bit plane does not describe them -> NaN, loudly
     int* s_words = reinterpret_cast<int*>(smem + 2 * K1S_RING);        // scratch words behind red[] (the rings are free now)
-    if (!REAL && a.aflag) {
+    if (a.amode == K1S_ASSERTED) {
         int bad = 0;
         for (int i = tid; i < wd * 8; i += 256) bad |= a.aflag[(z * 8 + i / wd) * a.ncb + cb0 + (i % wd)] & FLAG_NONBINARY;
         if (l == 0) s_words[4 + w] = 0;
@@ -396,8 +415,8 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     }
     stamp(st, sblk, 5);
     // ---- epilogue of `finish`, fused: bias, sigmoid, Bernoulli sample, operand forms, column sums
-    if (fa.lean) (void)finish_lean8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, sl8, 1, 32);
-    else         (void)finish_rows8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, side);
+    if (!GE || fa.lean) (void)finish_lean8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, sl8, 1, 32);
+    else if constexpr (GE) (void)finish_rows8(fa, ecol, mb + 8 * oct, xs, (mb >> 3) + oct, side);
     stamp(st, sblk, 6);
 }
 

@@ -92,8 +92,9 @@ def _check_term_loop_counts(name, body, na):
             plain += 1
         m = re.match(r"s_waitcnt vmcnt\((\d+)\)", l) if in_asm else None
         if m:
-            if counting:      # the step that started with the steady-state wait: its refills up to the next hand-written vmcnt wait
-                assert dma == 2 * na + 2 and plain == 0, f"{name}: {dma} LDS-DMA / {plain} register loads per step, the waits assume {2 * na + 2} / 0"
+            # the step that started with the steady-state wait: its refills up to the next hand-written vmcnt wait (the prologue's
+            # wait for the bit plane can have the same count: such segments are not steps and are skipped)
+            if counting and dma == 2 * na + 2 and plain == 0:
                 seen += 1
             counting = int(m.group(1)) == steady
             dma = plain = 0
@@ -109,10 +110,17 @@ def test_streaming_kernels_have_no_scratch_and_only_the_planned_counts(functions
         planned = {0, 12, 16}                                 # 0, 4 (D - 1), 4 D  (kernels_stream.hpp K1S_D = 4): the bit-plane loop
         if na:
             planned |= {4 * na, 4 * na + 2, 4 * na + 4, 4 * na + 6}       # loop over bf16 terms: A(i+1) A(i+2) [+ W(i+3)] [+ W(i+4)] [+ W(i+5)] may stay in flight
+            planned |= {12 + 2, 16 + 2}                                   # bit-plane loop with the 2 exactness-map loads issued behind the first ring slots
         assert counts <= planned, (name, counts)
         assert not any(l.startswith("scratch_") for l in body), f"{name} spills to scratch"
         if na:
             _check_term_loop_counts(name, body, na)
+        # everything these kernels keep in flight is LDS-DMA: a register-destination load written in inline asm is regarded as ready at
+        # once by the compiler, which then copies its destination around before the wait that makes it valid (seen twice in round 3)
+        in_asm = False
+        for l in body:
+            in_asm = l.startswith(";;#ASMSTART") or (in_asm and not l.startswith(";;#ASMEND"))
+            assert not (in_asm and re.match(r"(global|buffer|flat)_load_(dword|ushort|ubyte)", l)), f"{name}: register load in inline asm: {l}"
     for name, body in functions.items():
         if "k2_streamILi" in name:
             assert not any(l.startswith("scratch_") for l in body), f"{name} spills to scratch"

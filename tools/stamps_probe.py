@@ -15,20 +15,23 @@ V, H, B = 10000, 1500, 64
 dev = torch.device("cuda")
 eng = E.get_hip_engine()
 rbm = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
-x = (torch.rand(B, V) > 0.9).float().to(dev)
+xs = [(torch.rand(B, V) > 0.9).float().to(dev) for _ in range(4)]
+if "--tag" in sys.argv:
+    for t in xs: t._imdbn_binary = True
 E.set_rng(E.PhiloxRng(seed=2))
-for which, bit, nslots in (("K1 k1_stream (last launch = negative phase): start, bits+ring landed, loop done, reduced, published, [last arriver:] combined, epilogue done", 64, 7),
+for which, bit, nslots in (("K1 k1_stream POSITIVE phase: start, bits+ring landed, loop done, reduced, published, [last arriver:] combined, epilogue done", 2048, 7),
+                           ("K1 k1_stream (last launch = negative phase): start, bits+ring landed, loop done, reduced, published, [last arriver:] combined, epilogue done", 64, 7),
                            ("K2 k2_stream: start, bits staged, loop done, reduced, epilogue done, loss done", 128, 6),
                            ("K3 assoc_update_planes", 512, 6)):
     eng.set_option("dbg", bit)
     for i in range(20):
-        rbm.train_epoch(x, 0, 1, CD=1)
+        rbm.train_epoch(xs[i % 4], 0, 1, CD=1, next_data=xs[(i + 1) % 4])
     torch.cuda.synchronize()
     buf = (C.c_longlong * (4096 * 8))()
     native.check(native.lib().imdbn_debug_stamps(buf, 4096 * 8), "imdbn_debug_stamps")
     a = np.frombuffer(buf, dtype=np.int64).reshape(4096, 8).copy()
     nb = int((a[:, 0] > 0).sum())
-    if bit == 64:      # k1_stream: only the last arriver of a tile has slots 5, 6
+    if bit in (64, 2048):      # k1_stream: only the last arriver of a tile has slots 5, 6
         last = a[:nb][a[:nb, 6] > 0]
         b = last[:, :7].astype(np.float64) / 100.0
         b -= a[:nb, 0].min() / 100.0

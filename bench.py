@@ -316,12 +316,14 @@ def main():
 
     def timed_region(k3_events: bool):
         """W warm-up steps, then exactly K steps between barrier + synchronize pairs; max over the ranks."""
+        if k3_events:
+            eng.profile(True)      # (creates the event pool on first use: before the warm-up, so that the GPU does not sit idle behind it)
         for i in range(args.warmup):
             step(i)
         sync()
         i0 = args.warmup
         if k3_events:
-            eng.profile(True)
+            eng.profile(True)      # resets the counters: only launches of the timed region are bracketed
         t0 = time.perf_counter()
         stamps = []
         for i in range(i0, i0 + args.steps):      # continues the batch sequence of the warm-up steps

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IMDBN_ABI_VERSION 3
+#define IMDBN_ABI_VERSION 4
 
 /* error codes (negative) */
 #define IMDBN_E_INVALID   (-1)   /* bad argument (shape, null pointer, alignment) */
@@ -281,6 +281,18 @@ int imdbn_rbm_chain(const imdbn_rbm_desc* d, const float* v_known, const float* 
                     int init_uniform, int n_steps, const imdbn_chain_step* steps,
                     const float* mu, int64_t ldmu, int Dz, imdbn_rng* rng,
                     float* out_v, int64_t ldo, void* ws, size_t ws_bytes, imdbn_stream_t stream);
+
+/* Two independent chains of the same RBM and batch size as ONE call (iMDBN._cross_reconstruct, imdbn.py:419-449: its IMG->TXT
+ * and TXT->IMG chains share nothing but the read-only weights).  Equivalent, bit for bit, to imdbn_rbm_chain(a) followed by
+ * imdbn_rbm_chain(b) on the same rng; where the row-parallel chain kernel applies the two run in one launch, side by side. */
+typedef struct imdbn_chain_spec {
+    const float* v_known; const float* mask; int64_t ldk;   /* [B][V] clamp values and 0/1 mask (same row stride) */
+    int32_t init_uniform; int32_t n_steps; const imdbn_chain_step* steps;
+    const float* mu; int64_t ldmu; int32_t Dz; int32_t _pad; /* mu-pull target [B][Dz] (nullable) */
+    float* out_v; int64_t ldo;                              /* final visible state [B][V] */
+} imdbn_chain_spec;
+int imdbn_rbm_chain_pair(const imdbn_rbm_desc* d, int B, const imdbn_chain_spec* a, const imdbn_chain_spec* b,
+                         imdbn_rng* rng, void* ws, size_t ws_bytes, imdbn_stream_t stream);
 
 /* ---- whole RBM.train_epoch_clamped (rbm.py:402-483) -------------------------------------- */
 /* positive phase = chain(n_init steps) ; negative = cd_k steps from v+ ; update with o->lr */

@@ -50,6 +50,7 @@ struct Tuning {
     int no_k1s_real = 0;             // testing: real-valued operands of K1 take the partial GEMM + finish launches, not k1_stream
     int no_adaptive = 0;             // testing: a prefetched batch of unknown content gets all three-term forms (no per-item choice)
     int k1s_lds_pad = 0;             // experiment: extra dynamic LDS (bytes) for the bit-plane k1_stream
+    int no_chain_pair = 0;           // testing: imdbn_rbm_chain_pair runs its chains one after the other
     int k1s_force_na = 0;            // experiment: bit-plane operands run on the kernel instantiation that can also read bf16 terms
 };
 Tuning g_defaults;
@@ -76,6 +77,7 @@ inline const Tuning& tune() { return t_bound ? *t_bound : g_defaults; }
 #define g_no_adaptive (tune().no_adaptive)
 #define g_k1s_lds_pad (tune().k1s_lds_pad)
 #define g_k1s_force_na (tune().k1s_force_na)
+#define g_no_chain_pair (tune().no_chain_pair)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
@@ -105,7 +107,8 @@ struct Prof {
     bool on = false;
     std::vector<hipEvent_t> ev;   // pairs
     size_t used = 0;
-    unsigned calls = 0;           // only every 4th update launch is bracketed: the event records perturb the stream
+    unsigned calls = 0;           // only every 8th update launch is bracketed (the 4th, 12th, ...): a bracket costs the stream ~10 us
+                                  // (two event records: measured in the kernel trace as +5 us on the bracketed step and +5 on the next)
 } g_prof;
 
 // ---- split-K plan --------------------------------------------------------------------------
@@ -529,14 +532,16 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
             const size_t lds = (size_t)((nsteps * 256 + 255) & ~255) + (size_t)std::max(K2S_LW * 16 * MT * K2S_LDR * 4, 64);
             dim3 grid(nbx, 1, mb);
             hipError_t le = hipSuccess;
-#define LAUNCH_K2S(NW, MTV) do { \
+#define LAUNCH_K2S(NW, MTV, GEV) do { \
         static bool attr = false; \
-        if (!attr) { le = hipFuncSetAttribute((const void*)k2_stream<NW, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        if (le == hipSuccess) hipLaunchKernelGGL((k2_stream<NW, MTV>), grid, dim3(64 * K2S_W), lds, c.s, a, f); } while (0)
-#define LAUNCH_K2S_M(NW) do { if (MT == 1) LAUNCH_K2S(NW, 1); else if (MT == 2) LAUNCH_K2S(NW, 2); else LAUNCH_K2S(NW, 3); } while (0)
+        if (!attr) { le = hipFuncSetAttribute((const void*)k2_stream<NW, MTV, GEV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        if (le == hipSuccess) hipLaunchKernelGGL((k2_stream<NW, MTV, GEV>), grid, dim3(64 * K2S_W), lds, c.s, a, f); } while (0)
+#define LAUNCH_K2S_G(NW, MTV) do { if (f.lean) LAUNCH_K2S(NW, MTV, false); else LAUNCH_K2S(NW, MTV, true); } while (0)
+#define LAUNCH_K2S_M(NW) do { if (MT == 1) LAUNCH_K2S_G(NW, 1); else if (MT == 2) LAUNCH_K2S_G(NW, 2); else LAUNCH_K2S_G(NW, 3); } while (0)
             if (lds > 160 * 1024) return fail(IMDBN_E_UNSUPPORTED, "internal: k2_stream LDS");
             if (c.nw == 3) LAUNCH_K2S_M(3); else LAUNCH_K2S_M(1);
 #undef LAUNCH_K2S_M
+#undef LAUNCH_K2S_G
 #undef LAUNCH_K2S
             HIPCHK(le);
             HIPCHK(hipGetLastError());
@@ -648,7 +653,7 @@ int launch_assoc(Ctx& c, int mode_stats, const imdbn_cd_opts* o, int vpos_terms,
     a.vts = (int64_t)L.V * L.Bp; a.hts = (int64_t)L.H * L.Bp; a.Bp = L.Bp;
     a.lr = o->lr; a.mom = o->momentum; a.wd = o->weight_decay; a.n = n;
     a.delta = delta;
-    const bool prof = g_prof.on && !mode_stats && (g_prof.calls++ % 4 == 0) && g_prof.used + 2 <= g_prof.ev.size();
+    const bool prof = g_prof.on && !mode_stats && (g_prof.calls++ % 8 == 3) && g_prof.used + 2 <= g_prof.ev.size();
     if (prof) HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], c.s));
     // fast path: every W / W_m / delta row start 16-B aligned -> float4 weight tiles, LDS-staged planes
     const bool fast = L.H % 4 == 0 && L.H >= 4 && c.d->ldw % 4 == 0 && (((uintptr_t)c.d->W) & 15) == 0 &&
@@ -792,33 +797,67 @@ bool chain_kernel_ok(const Ctx& c, int n_steps) {
     return gw <= GROUP_WMAX && lds <= (size_t)K4_LDS_BYTES;
 }
 
-int run_chain_k4(Ctx& c, const float* vk, const float* mask, int64_t ldk, int n_steps, const imdbn_chain_step* st,
-                 const float* mu, int64_t ldmu, int Dz, float* out, int64_t ldo, bool want_stats) {
+// One chain as the host sees it (imdbn_chain_spec + where its final state goes)
+struct ChainSpec {
+    const float* vk; const float* mask; int64_t ldk; int init_uniform; int n_steps; const imdbn_chain_step* st;
+    const float* mu; int64_t ldmu; int Dz; float* out; int64_t ldo;
+};
+
+// v0 = vk*m + (1-m)*U   (rbm.py:271,333,392) into `out` (and, for the per-launch path, the operand forms of vis_rm[0])
+int chain_init(Ctx& c, const ChainSpec& s, bool forms, bool stats_now) {
+    const Layout& L = c.L;
+    const int B = L.B;
+    PrepArgs p;
+    memset(&p, 0, sizeof(p));
+    p.in = s.vk; p.ld = s.ldk; p.B = B; p.Bp = L.Bp; p.N = L.V;
+    if (s.init_uniform) { p.mix = 1; p.mask = s.mask; p.ldm = s.ldk; p.uni = c.rng.floats(B, L.V); }
+    p.out_f32 = s.out; p.ldo = s.ldo;
+    p.op.ldrm = L.Vpad; p.op.rm_ts = (int64_t)L.Bp * L.Vpad; p.op.Bp = L.Bp;
+    if (forms) { p.op.rm = L.vis_rm[0]; p.op.rm_terms = c.rt; }
+    if (stats_now) {
+        p.op.tr = L.vis_tr[0]; p.op.tr_ts = (int64_t)L.V * L.Bp; p.op.tr_terms = c.rt;
+        p.colsum_part = L.cs_vpos;
+    }
+    hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Vpad, 64), L.P), dim3(256), 0, c.s, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// draw cursors of a chain's steps in exactly the order of the per-launch path, written as records [off, off + n_steps)
+int chain_records(Ctx& c, const ChainSpec& s, int off) {
     const Layout& L = c.L;
     const imdbn_rbm_desc* d = c.d;
     const int B = L.B;
-    // draw cursors in exactly the order of the per-launch path below
     ChainRecBatch batch;
-    for (int t0 = 0; t0 < n_steps; t0 += CHAIN_REC_BATCH) {
-        const int n = std::min(CHAIN_REC_BATCH, n_steps - t0);
+    for (int t0 = 0; t0 < s.n_steps; t0 += CHAIN_REC_BATCH) {
+        const int n = std::min(CHAIN_REC_BATCH, s.n_steps - t0);
         memset(&batch, 0, sizeof(batch));
         for (int i = 0; i < n; ++i) {
-            const imdbn_chain_step& s = st[t0 + i];
+            const imdbn_chain_step& st = s.st[t0 + i];
             ChainRec& r = batch.r[i];
-            r.T = s.T; r.sigma = s.sigma; r.eta = s.eta;
-            r.flags = (s.sample_h ? 1 : 0) | ((s.vmode & 3) << 1) | (s.clamp ? 8 : 0);
+            r.T = st.T; r.sigma = st.sigma; r.eta = st.eta;
+            r.flags = (st.sample_h ? 1 : 0) | ((st.vmode & 3) << 1) | (st.clamp ? 8 : 0);
             auto cd = [](const DrawSrc& x) { ChainDraw y; y.tape = x.tape; y.draw = x.draw; return y; };
-            if (s.sigma > 0.f) r.noise_h = cd(c.rng.floats(B, L.H));
-            if (s.sample_h) r.uni_h = cd(c.rng.floats(B, L.H));
-            if (s.sigma > 0.f) r.noise_v = cd(c.rng.floats(B, L.V));
-            if (s.vmode != 0) {
+            if (st.sigma > 0.f) r.noise_h = cd(c.rng.floats(B, L.H));
+            if (st.sample_h) r.uni_h = cd(c.rng.floats(B, L.H));
+            if (st.sigma > 0.f) r.noise_v = cd(c.rng.floats(B, L.V));
+            if (st.vmode != 0) {
                 r.uni_v = cd(c.rng.floats(B, L.V));
                 DrawSrc cu; c.rng.cats(B, d->n_groups, &r.cat_tape, &cu);
                 r.cat_uni = cd(cu);
             }
         }
-        hipLaunchKernelGGL(chain_write_recs, dim3(1), dim3(64), 0, c.s, batch, L.chain_recs + t0, n);
+        hipLaunchKernelGGL(chain_write_recs, dim3(1), dim3(64), 0, c.s, batch, L.chain_recs + off + t0, n);
     }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the chain kernel for one chain (s1 == nullptr) or two independent ones of the same RBM in one launch
+int launch_k4(Ctx& c, const ChainSpec& s0, int off0, const ChainSpec* s1, int off1) {
+    const Layout& L = c.L;
+    const imdbn_rbm_desc* d = c.d;
+    const int B = L.B;
     {
         const dim3 sg(std::max(cdiv(L.H, 16), cdiv(L.V, 16)), std::max(cdiv(L.V, 32), cdiv(L.H, 32)), 2);
         if (c.nw == 3) hipLaunchKernelGGL(k4_split_planes<2>, sg, dim3(64), 0, c.s, d->W, d->ldw, L.V, L.H, L.k4_planes, L.k4_plane_stride);
@@ -827,53 +866,52 @@ int run_chain_k4(Ctx& c, const float* vk, const float* mask, int64_t ldk, int n_
     K4Args a;
     memset(&a, 0, sizeof(a));
     a.planes = L.k4_planes; a.plane_stride = L.k4_plane_stride;
-    a.V = L.V; a.H = L.H; a.B = B; a.nw = c.nw; a.rt = c.rt;
+    a.V = L.V; a.H = L.H; a.nw = c.nw; a.rt = c.rt;
     a.hid_bias = d->hid_bias; a.vis_bias = d->vis_bias;
     a.n_groups = d->n_groups;
     for (int g = 0; g < IMDBN_MAX_GROUPS; ++g) { a.gs[g] = d->group_start[g]; a.ge[g] = d->group_end[g]; }
-    a.state = out; a.lds = ldo;
-    a.recs = L.chain_recs; a.n_steps = n_steps;
     a.seed = c.rng.r ? c.rng.r->seed : 0; a.row0 = c.rng.r ? c.rng.r->row0 : 0;
     a.draw_base = c.rng.r ? (const unsigned long long*)c.rng.r->dev_offset : nullptr;
-    a.mu = mu; a.ldmu = ldmu; a.Dz = Dz;
-    a.vk = vk; a.mask = mask; a.ldk = ldk;
+    auto seg = [&](const ChainSpec& s, int off) {
+        K4Seg g;
+        g.state = s.out; g.lds = s.ldo; g.recs = L.chain_recs + off; g.n_steps = s.n_steps;
+        g.mu = s.mu; g.ldmu = s.ldmu; g.Dz = s.Dz; g.vk = s.vk; g.mask = s.mask; g.ldk = s.ldk; g.B = B;
+        return g;
+    };
+    a.s0 = seg(s0, off0);
+    a.s1 = s1 ? seg(*s1, off1) : a.s0;
     // rows per block: enough blocks to spread the per-element work (Philox, Box-Muller, sigmoid) over the CUs;
     // one block per CU at most (every block streams all of W from L2)
     a.dbg = (g_dbg & 1024) ? 1 : 0;
-    a.rows = g_k4_rows > 0 ? g_k4_rows : (B <= 2 * cu_count() ? 2 : (B <= 4 * cu_count() ? 4 : (B <= 8 * cu_count() ? 8 : 16)));      // measured: 0.90 / 0.99 / 1.19 / 1.59 ms for 2 / 4 / 8 / 16 rows (30 steps, 532<->256)
-    if (c.nw == 3) hipLaunchKernelGGL(k4_chain<2>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);      // PARITY: fp16 hi + lo terms
-    else           hipLaunchKernelGGL(k4_chain<1>, dim3(cdiv(B, a.rows)), dim3(64 * K4_WAVES), 0, c.s, a);
+    const int nch = s1 ? 2 : 1, BT = B * nch;
+    a.rows = g_k4_rows > 0 ? g_k4_rows : (BT <= 2 * cu_count() ? 2 : (BT <= 4 * cu_count() ? 4 : (BT <= 8 * cu_count() ? 8 : 16)));      // measured: 0.90 / 0.99 / 1.19 / 1.59 ms for 2 / 4 / 8 / 16 rows (30 steps, 532<->256)
+    a.nblk0 = cdiv(B, a.rows);
+    const dim3 grid(a.nblk0 * nch);
+    if (c.nw == 3) hipLaunchKernelGGL(k4_chain<2>, grid, dim3(64 * K4_WAVES), 0, c.s, a);      // PARITY: fp16 hi + lo terms
+    else           hipLaunchKernelGGL(k4_chain<1>, grid, dim3(64 * K4_WAVES), 0, c.s, a);
     HIPCHK(hipGetLastError());
-    // operand forms of the final state (what the last v|h launch of the per-launch path leaves behind)
-    CHK(prep(c, out, ldo, L.V, L.vis_rm[0], L.Vpad, want_stats ? L.vis_tr[0] : nullptr, nullptr, want_stats ? L.cs_vpos : nullptr, c.rt));
-    c.hid_bits_ok = false;
     return 0;
 }
 
-// chain: init + steps.  The final state ends in fp32 `out` (ld ldo) and in vis_rm[0] (rt terms).
-// want_stats: additionally leave the transposed form in vis_tr[0] and column sums in cs_vpos.
-int run_chain(Ctx& c, const float* vk, const float* mask, int64_t ldk, int init_uniform, int n_steps,
-              const imdbn_chain_step* st, const float* mu, int64_t ldmu, int Dz, float* out, int64_t ldo, bool want_stats) {
+// chain: init + steps.  The final state ends in fp32 `out` (ld ldo); with want_stats also as operand forms in vis_rm[0] (rt terms),
+// the transposed form in vis_tr[0] and column sums in cs_vpos (the positive phase of the clamped update).
+int run_chain(Ctx& c, const ChainSpec& s, bool want_stats) {
     const Layout& L = c.L;
     const int B = L.B;
+    const float* vk = s.vk; const float* mask = s.mask; const int64_t ldk = s.ldk, ldo = s.ldo, ldmu = s.ldmu;
+    const int n_steps = s.n_steps, Dz = s.Dz; const imdbn_chain_step* st = s.st; const float* mu = s.mu; float* out = s.out;
     if (n_steps < 0 || (n_steps > 0 && !st)) return fail(IMDBN_E_INVALID, "bad chain steps");
     if (mu && (Dz <= 0 || Dz > L.V)) return fail(IMDBN_E_INVALID, "mu-pull width %d outside (0,%d]", Dz, L.V);
-    {   // v0 = vk*m + (1-m)*U   (rbm.py:271,333,392)
-        PrepArgs p;
-        memset(&p, 0, sizeof(p));
-        p.in = vk; p.ld = ldk; p.B = B; p.Bp = L.Bp; p.N = L.V;
-        if (init_uniform) { p.mix = 1; p.mask = mask; p.ldm = ldk; p.uni = c.rng.floats(B, L.V); }
-        p.out_f32 = out; p.ldo = ldo;
-        p.op.rm = L.vis_rm[0]; p.op.ldrm = L.Vpad; p.op.rm_ts = (int64_t)L.Bp * L.Vpad; p.op.rm_terms = c.rt; p.op.Bp = L.Bp;
-        if (want_stats && n_steps == 0) {
-            p.op.tr = L.vis_tr[0]; p.op.tr_ts = (int64_t)L.V * L.Bp; p.op.tr_terms = c.rt;
-            p.colsum_part = L.cs_vpos;
-        }
-        hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Vpad, 64), L.P), dim3(256), 0, c.s, p);
-        HIPCHK(hipGetLastError());
+    const bool k4 = chain_kernel_ok(c, n_steps);
+    CHK(chain_init(c, s, !k4 || n_steps == 0, want_stats && n_steps == 0));
+    if (k4) {
+        CHK(chain_records(c, s, 0));
+        CHK(launch_k4(c, s, 0, nullptr, 0));
+        // operand forms of the final state (what the last v|h launch of the per-launch path leaves behind): only the clamped update reads them
+        if (want_stats) CHK(prep(c, out, ldo, L.V, L.vis_rm[0], L.Vpad, L.vis_tr[0], nullptr, L.cs_vpos, c.rt));
+        c.hid_bits_ok = false;
+        return 0;
     }
-    if (chain_kernel_ok(c, n_steps))
-        return run_chain_k4(c, vk, mask, ldk, n_steps, st, mu, ldmu, Dz, out, ldo, want_stats);
     for (int t = 0; t < n_steps; ++t) {
         const imdbn_chain_step& s = st[t];
         const bool last = (t == n_steps - 1);
@@ -965,6 +1003,7 @@ static int set_opt(Tuning& t, const char* name, int value) {
     else if (!strcmp(name, "no_k1s_real")) t.no_k1s_real = value;
     else if (!strcmp(name, "no_adaptive")) t.no_adaptive = value;
     else if (!strcmp(name, "k1s_force_na")) t.k1s_force_na = value;
+    else if (!strcmp(name, "no_chain_pair")) t.no_chain_pair = value;
     else if (!strcmp(name, "k1s_lds_pad")) t.k1s_lds_pad = std::max(0, std::min(value, 64 * 1024));
     else if (!strcmp(name, "no_fused_up")) t.no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);
@@ -1411,7 +1450,7 @@ static int apply_factors_impl(const imdbn_rbm_desc* d, const void* head, size_t 
     const int tpb = std::max(1, cdiv(nh * nv, std::max(cu_count(), 1)));
     const int brows = nh >= 2 ? 1 : 2;
     // (bench.py roofline at N > 1: the update kernel bracketed with HIP events on its stream, every 4th call)
-    const bool prof = g_prof.on && (g_prof.calls++ % 4 == 0) && g_prof.used + 2 <= g_prof.ev.size();
+    const bool prof = g_prof.on && (g_prof.calls++ % 8 == 3) && g_prof.used + 2 <= g_prof.ev.size();
     if (prof) HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], c.s));
     auto prof_end = [&]() -> int { if (prof) { HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], c.s)); g_prof.used += 2; } return 0; };
     // all rank blocks inside one launch (the weights move once) when the visible operands need <= 4 plane slices
@@ -1493,7 +1532,38 @@ int imdbn_rbm_chain(const imdbn_rbm_desc* d, const float* v_known, const float* 
     if (!v_known || !mask || !out_v || ldk < d->V || ldo < d->V) return fail(IMDBN_E_INVALID, "chain: bad argument");
     Ctx c(d, rng, S(stream));
     CHK(setup(c, B, ws, ws_bytes));
-    CHK(run_chain(c, v_known, mask, ldk, init_uniform, n_steps, steps, mu, ldmu, Dz, out_v, ldo, false));
+    CHK(run_chain(c, ChainSpec{v_known, mask, ldk, init_uniform, n_steps, steps, mu, ldmu, Dz, out_v, ldo}, false));
+    return c.rng.finish();
+}
+
+// Two independent chains of the same RBM and batch size in one call (imdbn.py:419-449: the IMG->TXT and TXT->IMG chains of
+// _cross_reconstruct share nothing but the read-only weights).  Draws are assigned in the order of two imdbn_rbm_chain calls (a, then b),
+// so the results are those of the two calls, bit for bit; where the row-parallel chain kernel applies both run in ONE launch
+// (chain a on the first half of the grid, chain b on the second).
+int imdbn_rbm_chain_pair(const imdbn_rbm_desc* d, int B, const imdbn_chain_spec* a, const imdbn_chain_spec* b, imdbn_rng* rng,
+                         void* ws, size_t ws_bytes, imdbn_stream_t stream) {
+    CHK(check_desc(d, false));
+    if (!a || !b) return fail(IMDBN_E_INVALID, "chain_pair: null chain");
+    for (const imdbn_chain_spec* s : {a, b})
+        if (!s->v_known || !s->mask || !s->out_v || s->ldk < d->V || s->ldo < d->V || s->n_steps < 0 || (s->n_steps > 0 && !s->steps) ||
+            (s->mu && (s->Dz <= 0 || s->Dz > d->V)))
+            return fail(IMDBN_E_INVALID, "chain_pair: bad argument");
+    if (a->out_v == b->out_v) return fail(IMDBN_E_INVALID, "chain_pair: the two chains need separate output buffers");
+    Ctx c(d, rng, S(stream));
+    CHK(setup(c, B, ws, ws_bytes));
+    const ChainSpec sa{a->v_known, a->mask, a->ldk, a->init_uniform, a->n_steps, a->steps, a->mu, a->ldmu, a->Dz, a->out_v, a->ldo};
+    const ChainSpec sb{b->v_known, b->mask, b->ldk, b->init_uniform, b->n_steps, b->steps, b->mu, b->ldmu, b->Dz, b->out_v, b->ldo};
+    if (chain_kernel_ok(c, sa.n_steps) && chain_kernel_ok(c, sb.n_steps) && sa.n_steps + sb.n_steps <= CHAIN_MAX_STEPS && !g_no_chain_pair) {
+        CHK(chain_init(c, sa, false, false));
+        CHK(chain_records(c, sa, 0));
+        CHK(chain_init(c, sb, false, false));
+        CHK(chain_records(c, sb, sa.n_steps));
+        CHK(launch_k4(c, sa, 0, &sb, sa.n_steps));
+        c.hid_bits_ok = false;
+    } else {
+        CHK(run_chain(c, sa, false));
+        CHK(run_chain(c, sb, false));
+    }
     return c.rng.finish();
 }
 
@@ -1506,7 +1576,7 @@ static int clamped_phases(Ctx& c, const float* v_known, const float* mask, int64
     const Layout& L = c.L;
     float* vplus = L.f_v[0];
     // positive phase: v+ by conditional inference (rbm.py:443-453), H+ = up(v+) (:455)
-    CHK(run_chain(c, v_known, mask, ldk, 1, n_init, init_steps, mu, ldmu, Dz, vplus, L.V, true));
+    CHK(run_chain(c, ChainSpec{v_known, mask, ldk, 1, n_init, init_steps, mu, ldmu, Dz, vplus, (int64_t)L.V}, true));
     for (int it = 0; it < o->cd_k; ++it) {
         {   // h_prob = up(v_neg) ; first iteration: v_neg == v+ so this is also H+
             FinishArgs f = new_finish();

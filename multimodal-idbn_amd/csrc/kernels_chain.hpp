@@ -105,17 +105,24 @@ __global__ __launch_bounds__(64) void k4_split_planes(const float* __restrict__ 
     }
 }
 
-struct K4Args {
-    const bf16_t* planes; int64_t plane_stride;     // [2][3] planes
-    int V, H, B, nw, rt;                           // nw weight terms, rt terms of a real-valued activation
-    const float* hid_bias; const float* vis_bias;
-    int n_groups; int gs[4]; int ge[4];
+// One chain of a launch: its rows, clamp inputs, mu-pull, schedule and state.  A launch runs one chain or TWO independent ones of the
+// same RBM (imdbn_rbm_chain_pair: the IMG->TXT and TXT->IMG chains of iMDBN._cross_reconstruct, imdbn.py:419-449, share nothing but
+// the read-only weights): blocks [0, nblk0) belong to chain 0, the rest to chain 1 -- twice the CUs busy for the time of one chain.
+struct K4Seg {
     float* state; int64_t lds;                     // fp32 visible state [B][V]: v0 in, final v out
-    int rows;                                      // batch rows per block (<= 16): fewer rows = more CUs share the element-wise work
     const ChainRec* recs; int n_steps;
-    uint64_t seed; int64_t row0; const unsigned long long* draw_base;
     const float* mu; int64_t ldmu; int Dz;
     const float* vk; const float* mask; int64_t ldk;
+    int B;
+};
+struct K4Args {
+    const bf16_t* planes; int64_t plane_stride;     // [2][3] planes
+    int V, H, nw, rt;                              // nw weight terms, rt terms of a real-valued activation
+    const float* hid_bias; const float* vis_bias;
+    int n_groups; int gs[4]; int ge[4];
+    int rows;                                      // batch rows per block (<= 16): fewer rows = more CUs share the element-wise work
+    uint64_t seed; int64_t row0; const unsigned long long* draw_base;
+    K4Seg s0, s1; int nblk0;                       // chain 0 owns blocks [0, nblk0), chain 1 the rest
     int dbg;                                       // 1: per-block stamps of chain step 2 (tools/stamps_probe.py)
 };
 
@@ -247,7 +254,14 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     __shared__ __attribute__((aligned(16))) char smem[K4_LDS_BYTES];
     const int tid = threadIdx.x;
     const int RB = a.rows;                                                          // valid rows of this block; MFMA rows >= RB are zero
-    const int b0 = blockIdx.x * RB;
+    // this block's chain (block-uniform; selected member by member: an indexed struct would live in scratch)
+    const bool second = (int)blockIdx.x >= a.nblk0;
+    const int b0 = ((int)blockIdx.x - (second ? a.nblk0 : 0)) * RB;
+    float* const c_state = second ? a.s1.state : a.s0.state; const int64_t c_lds = second ? a.s1.lds : a.s0.lds;
+    const ChainRec* const c_recs = second ? a.s1.recs : a.s0.recs; const int c_nsteps = second ? a.s1.n_steps : a.s0.n_steps;
+    const float* const c_mu = second ? a.s1.mu : a.s0.mu; const int64_t c_ldmu = second ? a.s1.ldmu : a.s0.ldmu; const int c_Dz = second ? a.s1.Dz : a.s0.Dz;
+    const float* const c_vk = second ? a.s1.vk : a.s0.vk; const float* const c_mask = second ? a.s1.mask : a.s0.mask;
+    const int64_t c_ldk = second ? a.s1.ldk : a.s0.ldk; const int c_B = second ? a.s1.B : a.s0.B;
     const int VK = (a.V + 31) / 32 * 32 + 8, HK = (a.H + 31) / 32 * 32 + 8;      // LDS row pitch (elements): 16-B skew against bank conflicts
     constexpr int at = NW;                                                          // activation terms kept (= a.rt)
     const int gs0 = a.gs[0], gwd = a.n_groups > 0 ? a.ge[0] - a.gs[0] : 0;          // the (single) softmax group
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     // v0 -> terms (pad columns and rows >= B are zero)
     for (int i = tid; i < K4_ROWS * (VK - 8); i += K4_THREADS) {
         const int row = i / (VK - 8), col = i - row * (VK - 8);
-        const float x = (col < a.V && row < RB && b0 + row < a.B) ? a.state[(int64_t)(b0 + row) * a.lds + col] : 0.f;
+        const float x = (col < a.V && row < RB && b0 + row < c_B) ? c_state[(int64_t)(b0 + row) * c_lds + col] : 0.f;
         k4_put<NW>(vact, VK, row, col, x, false);
     }
     for (int i = tid; i < at * K4_ROWS * HK; i += K4_THREADS) hact[i] = 0;          // pad columns and rows >= RB stay zero for the whole chain
@@ -273,14 +287,14 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
     const int RP = (RB + 1) / 2;                                  // row pairs of the block
     uint4 ring[K4_RING][NW];                                      // B-fragment ring of the GEMMs, pre-filled one phase ahead
     k4_prefetch<NW>(a, 0, NTu, KBu, ring);
-    for (int t = 0; t < a.n_steps; ++t) {
-        const ChainRec r = a.recs[t];
+    for (int t = 0; t < c_nsteps; ++t) {
+        const ChainRec r = c_recs[t];
         const bool st = a.dbg && t == 2;
         stamp(st, blockIdx.x, 0);
-        const bool sample_h = (r.flags & 1) != 0, clamp = (r.flags & 8) != 0, last = t == a.n_steps - 1;
+        const bool sample_h = (r.flags & 1) != 0, clamp = (r.flags & 8) != 0, last = t == c_nsteps - 1;
         const int vmode = (r.flags >> 1) & 3;
         const float T = fmaxf(r.T, 1e-6f);                       // max(1e-6, T)  rbm.py:92,96
-        const bool pull_on = a.mu && r.eta != 0.f;
+        const bool pull_on = c_mu && r.eta != 0.f;
         // ---- h | v  (rbm.py:81-92) -----------------------------------------------------------------
         k4_gemm<NW, NW>(a, 0, NTu, KBu, vact, VK, stage, SP, ring);
         k4_prefetch<NW>(a, 1, NTd, KBd, ring);                    // the v|h GEMM's first fragments travel during the h epilogue
@@ -298,14 +312,14 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                 if (i >= nh_items) {
                     const int j = i - nh_items, gp = j / gwd, gc = j - gp * gwd;
                     float zz[2] = {0.f, 0.f};
-                    draw_normal_rows2(nzv, b0 + 2 * gp, a.B - 1, gs0 + gc, zz);
+                    draw_normal_rows2(nzv, b0 + 2 * gp, c_B - 1, gs0 + gc, zz);
                     gz[(gp * gwd + gc) * 2 + 0] = zz[0]; gz[(gp * gwd + gc) * 2 + 1] = zz[1];
                     continue;
                 }
                 const int pr = i / a.H, col = i - pr * a.H;
                 float z2[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};
-                if (r.sigma > 0.f) draw_normal_rows2(nz, b0 + 2 * pr, a.B - 1, col, z2);
-                if (sample_h) draw_uniform_rows<2>(un, b0 + 2 * pr, a.B - 1, col, u2);
+                if (r.sigma > 0.f) draw_normal_rows2(nz, b0 + 2 * pr, c_B - 1, col, z2);
+                if (sample_h) draw_uniform_rows<2>(un, b0 + 2 * pr, c_B - 1, col, u2);
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int row = 2 * pr + hf;
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                     if (r.sigma > 0.f) x = x + z2[hf] * r.sigma;
                     float p = sigmoidf_ref(x);
                     if (sample_h) p = (p > u2[hf]) ? 1.f : 0.f;
-                    k4_put<NW>(hact, HK, row, col, (b0 + row < a.B) ? p : 0.f, sample_h);
+                    k4_put<NW>(hact, HK, row, col, (b0 + row < c_B) ? p : 0.f, sample_h);
                 }
             }
         }
@@ -335,14 +349,14 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                 float z2[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};
                 if (r.sigma > 0.f) {
                     if (in_group) { z2[0] = gz[(pr * gwd + (col - gs0)) * 2 + 0]; z2[1] = gz[(pr * gwd + (col - gs0)) * 2 + 1]; }   // drawn during the h epilogue
-                    else draw_normal_rows2(nz, b0 + 2 * pr, a.B - 1, col, z2);
+                    else draw_normal_rows2(nz, b0 + 2 * pr, c_B - 1, col, z2);
                 }
-                if (vmode != 0 && !in_group) draw_uniform_rows<2>(un, b0 + 2 * pr, a.B - 1, col, u2);
+                if (vmode != 0 && !in_group) draw_uniform_rows<2>(un, b0 + 2 * pr, c_B - 1, col, u2);
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int row = 2 * pr + hf;
                     if (row >= RB) break;
-                    const int b = b0 + row, bd = min(b, a.B - 1);
+                    const int b = b0 + row, bd = min(b, c_B - 1);
                     float x = stage[row * SP + col] + a.vis_bias[col];
                     if (T != 1.0f) x = x / T;
                     if (r.sigma > 0.f) x = x + z2[hf] * r.sigma;
@@ -351,9 +365,9 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                         continue;
                     }
                     float p = sigmoidf_ref(x);
-                    if (pull_on && col < a.Dz) p = (1.0f - r.eta) * p + r.eta * a.mu[(int64_t)bd * a.ldmu + col];
-                    const float m = clamp ? a.mask[(int64_t)bd * a.ldk + col] : 0.f;
-                    const float kn = clamp ? a.vk[(int64_t)bd * a.ldk + col] : 0.f;
+                    if (pull_on && col < c_Dz) p = (1.0f - r.eta) * p + r.eta * c_mu[(int64_t)bd * c_ldmu + col];
+                    const float m = clamp ? c_mask[(int64_t)bd * c_ldk + col] : 0.f;
+                    const float kn = clamp ? c_vk[(int64_t)bd * c_ldk + col] : 0.f;
                     const float mixed = clamp ? (p * (1.0f - m) + kn * m) : p;
                     float v;
                     if (vmode == 0) v = mixed;
@@ -362,9 +376,9 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
                         if (vmode == 1) { const float smp = (p > u) ? 1.f : 0.f; v = clamp ? (smp * (1.0f - m) + kn * m) : smp; }
                         else v = (mixed > u) ? 1.f : 0.f;
                     }
-                    if (b >= a.B) v = 0.f;
+                    if (b >= c_B) v = 0.f;
                     k4_put<NW>(vact, VK, row, col, v, false);
-                    if (last && b < a.B) a.state[(int64_t)b * a.lds + col] = v;
+                    if (last && b < c_B) c_state[(int64_t)b * c_lds + col] = v;
                 }
             }
         }
@@ -412,19 +426,19 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
             float* gt = stage;                                    // clipped sampling probabilities [RB][GW] (the stage is free now)
             if (vmode != 0 && !r.cat_tape) {
                 for (int i = tid; i < RB * gwd; i += K4_THREADS) {
-                    const int row = i / gwd, j = i - row * gwd, col = gs0 + j, bd = min(b0 + row, a.B - 1);
+                    const int row = i / gwd, j = i - row * gwd, col = gs0 + j, bd = min(b0 + row, c_B - 1);
                     float tt = glog[row * GW + j] / gaux[row * 4 + 1];
-                    if (pull_on && col < a.Dz) tt = (1.0f - r.eta) * tt + r.eta * a.mu[(int64_t)bd * a.ldmu + col];
+                    if (pull_on && col < c_Dz) tt = (1.0f - r.eta) * tt + r.eta * c_mu[(int64_t)bd * c_ldmu + col];
                     if (vmode == 2 && clamp) {
-                        const float m = a.mask[(int64_t)bd * a.ldk + col];
-                        tt = tt * (1.0f - m) + a.vk[(int64_t)bd * a.ldk + col] * m;
+                        const float m = c_mask[(int64_t)bd * c_ldk + col];
+                        tt = tt * (1.0f - m) + c_vk[(int64_t)bd * c_ldk + col] * m;
                     }
                     gt[row * GW + j] = fminf(fmaxf(tt, 1e-8f), 1.0f);
                 }
                 __syncthreads();
             }
             if (tid < RB) {
-                const int row = tid, bd = min(b0 + row, a.B - 1);
+                const int row = tid, bd = min(b0 + row, c_B - 1);
                 int idx = -1;
                 if (vmode != 0) {
                     if (r.cat_tape) idx = r.cat_tape[bd];
@@ -464,19 +478,19 @@ __global__ __launch_bounds__(K4_THREADS, 1) void k4_chain(const K4Args a) {
             }
             __syncthreads();
             for (int i = tid; i < RB * gwd; i += K4_THREADS) {
-                const int row = i / gwd, j = i - row * gwd, col = gs0 + j, b = b0 + row, bd = min(b, a.B - 1);
+                const int row = i / gwd, j = i - row * gwd, col = gs0 + j, b = b0 + row, bd = min(b, c_B - 1);
                 float p = glog[row * GW + j] / gaux[row * 4 + 1];
-                if (pull_on && col < a.Dz) p = (1.0f - r.eta) * p + r.eta * a.mu[(int64_t)bd * a.ldmu + col];
-                const float m = clamp ? a.mask[(int64_t)bd * a.ldk + col] : 0.f;
-                const float kn = clamp ? a.vk[(int64_t)bd * a.ldk + col] : 0.f;
+                if (pull_on && col < c_Dz) p = (1.0f - r.eta) * p + r.eta * c_mu[(int64_t)bd * c_ldmu + col];
+                const float m = clamp ? c_mask[(int64_t)bd * c_ldk + col] : 0.f;
+                const float kn = clamp ? c_vk[(int64_t)bd * c_ldk + col] : 0.f;
                 const int idx = __float_as_int(gaux[row * 4 + 2]);
                 float v;
                 if (vmode == 0) v = clamp ? (p * (1.0f - m) + kn * m) : p;
                 else if (vmode == 1) { const float o = (j == idx) ? 1.f : 0.f; v = clamp ? (o * (1.0f - m) + kn * m) : o; }
                 else v = (j == idx) ? 1.f : 0.f;
-                if (b >= a.B) v = 0.f;
+                if (b >= c_B) v = 0.f;
                 k4_put<NW>(vact, VK, row, col, v, false);
-                if (last && b < a.B) a.state[(int64_t)b * a.lds + col] = v;
+                if (last && b < c_B) c_state[(int64_t)b * c_lds + col] = v;
             }
         }
         __syncthreads();

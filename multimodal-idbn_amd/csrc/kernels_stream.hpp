@@ -449,7 +449,8 @@ struct K2sArgs {
 template <int MT>
 struct K2sOps { float4 w[MT][2]; };
 
-template <int NW, int MT>
+// GE: the general epilogue is compiled in (see k1_stream: the CD pass only needs the lean one, and dead code costs time here)
+template <int NW, int MT, bool GE>
 __global__ __launch_bounds__(64 * K2S_W, 2) void k2_stream(const K2sArgs a, const FinishArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bx = blockIdx.x, bz = blockIdx.z, nbx = gridDim.x;
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(64 * K2S_W, 2) void k2_stream(const K2sArgs a, cons
     SideIn<8> side;
     SideLean sl;
     if (isA || isB) {
-        if (fa.lean) load_side_lean(fa, ecol, mb + 8 * eoct, sl);
-        else         load_side<8>(fa, ecol, mb + 8 * eoct, side);
+        if (!GE || fa.lean) load_side_lean(fa, ecol, mb + 8 * eoct, sl);
+        else if constexpr (GE) load_side<8>(fa, ecol, mb + 8 * eoct, side);
     }
     if (w < K2S_LW) {
 #pragma unroll
@@ -560,8 +561,8 @@ __global__ __launch_bounds__(64 * K2S_W, 2) void k2_stream(const K2sArgs a, cons
             xs[i] = t;
         }
         const int bshape = isA ? 1 : 2, bcols = isA ? min(TR, 32) : TR - 32;
-        if (fa.lean) lsum = finish_lean8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, sl, bshape, bcols);
-        else         lsum = finish_rows8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, side, RmStage{}, bshape, bcols);
+        if (!GE || fa.lean) lsum = finish_lean8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, sl, bshape, bcols);
+        else if constexpr (GE) lsum = finish_rows8(fa, ecol, mb + 8 * eoct, xs, (mb >> 3) + eoct, side, RmStage{}, bshape, bcols);
     }
     stamp(st, sblk, 4);
     if (fa.loss_part) {

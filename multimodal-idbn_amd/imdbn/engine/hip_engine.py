@@ -619,6 +619,39 @@ class HipEngine:
         self._done(rng, r, sched)
         return out
 
+    def chain_pair(self, rbm, a: dict, b: dict, rng):
+        """Two independent chains of `rbm` on batches of the same size as one engine call (imdbn_rbm_chain_pair); each of `a`, `b` =
+        dict(v_known, mask, steps, init_uniform=True, mu=None).  Same draws, same results as ``chain(a)`` then ``chain(b)``."""
+        d = self._desc(rbm, False)
+        keep, specs, outs, sched = [], [], [], []
+        B = dev = None
+        for ch in (a, b):
+            vk, km = _f32c(ch["v_known"], "v_known"), _f32c(ch["mask"], "mask")
+            if vk.stride(0) != km.stride(0):
+                vk, km = vk.contiguous(), km.contiguous()
+            if B is None:
+                B, dev = vk.size(0), vk.device
+            elif vk.size(0) != B:
+                raise N.EngineError("chain_pair: the two chains need the same batch size")
+            steps, init_uniform = ch["steps"], bool(ch.get("init_uniform", True))
+            out = torch.empty(B, d.V, device=dev)
+            mu = ch.get("mu")
+            mu_t = _f32c(mu, "mu") if mu is not None else None
+            arr = self._steps(steps)
+            sp = N.ChainSpec()
+            sp.v_known, sp.mask, sp.ldk = vk.data_ptr(), km.data_ptr(), vk.stride(0)
+            sp.init_uniform, sp.n_steps, sp.steps = int(init_uniform), len(steps), arr
+            sp.mu, sp.ldmu, sp.Dz = (mu_t.data_ptr() if mu_t is not None else 0), (mu_t.stride(0) if mu_t is not None else 0), (mu_t.size(1) if mu_t is not None else 0)
+            sp.out_v, sp.ldo = out.data_ptr(), out.stride(0)
+            specs.append(sp); outs.append(out); keep.append((vk, km, mu_t, arr))
+            sched += R.sched_chain(d.V, d.H, self._groups(rbm), steps, init_uniform)
+        r, keep_r = self._rng(rng, sched, B, dev)
+        ws = self._workspace(dev, d.V, d.H, B)
+        N.check(self._lib.imdbn_rbm_chain_pair(C.byref(d), B, C.byref(specs[0]), C.byref(specs[1]), C.byref(r), _ptr(ws), ws.numel(),
+                                                self._stream(dev)), "imdbn_rbm_chain_pair")
+        self._done(rng, r, sched)
+        return outs[0], outs[1]
+
     def clamped_step(self, rbm, v_known, mask, init_steps: List[dict], mu, lr, mom, cd_k, sample_h, sample_v, reclamp, rng):
         d = self._desc(rbm, True)
         vk, km = _f32c(v_known, "v_known"), _f32c(mask, "mask")

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 MAX_GROUPS = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 PARITY_F32, FAST_BF16 = 0, 1
 RNG_PHILOX, RNG_REPLAY = 0, 1
 DATA_UNKNOWN, DATA_BINARY, DATA_REAL = 0, 1, 2      # imdbn_cd_opts.data_binary / next_binary (IMDBN_DATA_*)
@@ -43,6 +43,13 @@ class Rng(C.Structure):
 class ChainStep(C.Structure):
     _fields_ = [("T", C.c_float), ("sigma", C.c_float), ("eta", C.c_float),
                 ("sample_h", C.c_int32), ("vmode", C.c_int32), ("clamp", C.c_int32)]
+
+
+class ChainSpec(C.Structure):
+    _fields_ = [("v_known", C.c_void_p), ("mask", C.c_void_p), ("ldk", C.c_int64),
+                ("init_uniform", C.c_int32), ("n_steps", C.c_int32), ("steps", C.POINTER(ChainStep)),
+                ("mu", C.c_void_p), ("ldmu", C.c_int64), ("Dz", C.c_int32), ("_pad", C.c_int32),
+                ("out_v", C.c_void_p), ("ldo", C.c_int64)]
 
 
 class CdOpts(C.Structure):
@@ -99,6 +106,7 @@ SIGNATURES = {
     "imdbn_rbm_apply_factors": (_INT, [C.POINTER(RbmDesc), _P, _INT, _SZ, _INT, _INT, C.POINTER(CdOpts), _P, _P]),
     "imdbn_rbm_chain": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
                                C.POINTER(Rng), _P, _I64, _P, _SZ, _P]),
+    "imdbn_rbm_chain_pair": (_INT, [C.POINTER(RbmDesc), _INT, C.POINTER(ChainSpec), C.POINTER(ChainSpec), C.POINTER(Rng), _P, _SZ, _P]),
     "imdbn_rbm_clamped_step": (_INT, [C.POINTER(RbmDesc), _P, _P, _I64, _INT, _INT, C.POINTER(ChainStep), _P, _I64, _INT,
                                       C.POINTER(CdOpts), C.POINTER(Rng), _P, _P, _SZ, _P]),
     "imdbn_rbm_assoc_update": (_INT, [C.POINTER(RbmDesc), _P, _I64, _P, _I64, _P, _I64, _P, _I64, _INT, C.POINTER(CdOpts), _P, _SZ, _P]),

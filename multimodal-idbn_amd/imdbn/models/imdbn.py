@@ -234,24 +234,30 @@ class iMDBN(nn.Module):
         B, Dz, K = z_img.size(0), self.Dz_img, self.num_labels
         V = Dz + K
         jr = self.joint_rbm
-        # IMG -> TXT (:419-427)
+        # IMG -> TXT (:419-427) and TXT -> IMG with mu-pull (:430-449).  The reference runs the two chains one after the other; they
+        # share nothing but the joint RBM's read-only weights, so they go to the engine as one call (RBM._chain_pair: side by side
+        # in one launch, same draws in the same order, same results)
         v_known = torch.zeros(B, V, device=self.device)
         km = torch.zeros_like(v_known)
         v_known[:, :Dz] = z_img
         km[:, :Dz] = 1.0
-        v_img2txt = jr.conditional_gibbs(v_known, km, n_steps=steps, sample_h=False, sample_v=False)
-        p_y_given_img = v_img2txt[:, Dz:]
-        # TXT -> IMG with mu-pull (:430-449)
-        v_known.zero_()
-        km.zero_()
-        v_known[:, Dz:] = y_onehot
-        km[:, Dz:] = 1.0
+        vk_y = torch.zeros(B, V, device=self.device)
+        km_y = torch.zeros_like(vk_y)
+        vk_y[:, Dz:] = y_onehot
+        km_y[:, Dz:] = 1.0
         if getattr(self, "z_class_mean", None) is not None:
             jr._mu_pull = {"mu_k": self.z_class_mean[y_onehot.argmax(dim=1)], "eta0": 0.15}
         else:
             jr._mu_pull = None
-        v_chain = jr.noisy_meanfield_annealed(v_known=v_known, known_mask=km, n_steps=steps, T0=3.0, T1=1.0,
-                                              sigma0=0.9, hot_frac=0.7, sharpen_last=3, T_cold_plus=0.9)
+        gibbs = dict(v_known=v_known, known_mask=km, n_steps=steps, sample_h=False, sample_v=False)
+        nmf = dict(v_known=vk_y, known_mask=km_y, n_steps=steps, T0=3.0, T1=1.0, sigma0=0.9, hot_frac=0.7, sharpen_last=3, T_cold_plus=0.9)
+        if hasattr(jr, "_chain_pair"):
+            v_img2txt, v_chain = jr._chain_pair(gibbs, nmf)
+        else:
+            v_img2txt = jr.conditional_gibbs(**gibbs)
+            v_chain = jr.noisy_meanfield_annealed(**nmf)
+        p_y_given_img = v_img2txt[:, Dz:]
+        km = km_y
         if getattr(self, "live_best_of_k", False):
             v_chain = self._best_of_k(v_chain, km, max(1, int(getattr(self, "best_of_k", KBUF))))[0]
         else:

@@ -328,6 +328,25 @@ class RBM(nn.Module):
         steps.append(_step(clamp=False))
         return self._eng().chain(self, self._in(v_known), self._in(known_mask), steps, self._rng(v_known.size(0)))
 
+    @torch.no_grad()
+    def _chain_pair(self, gibbs: dict, nmf: dict):
+        """``conditional_gibbs(**gibbs)`` and ``noisy_meanfield_annealed(**nmf)`` (run in that order by the reference,
+        imdbn.py:424-449) as ONE engine call where the engine offers it: the two chains are independent (they share only the
+        read-only weights), so they run side by side in one launch.  Same draws in the same order, same results as the two calls.
+        Returns (v_gibbs, v_nmf)."""
+        eng = self._eng()
+        if not hasattr(eng, "chain_pair"):
+            return self.conditional_gibbs(**gibbs), self.noisy_meanfield_annealed(**nmf)
+        g = dict(n_steps=30, sample_h=False, sample_v=False); g.update(gibbs)
+        n = dict(n_steps=72, T0=3.0, T1=1.0, sigma0=0.9, hot_frac=0.7, sharpen_last=3, T_cold_plus=0.9); n.update(nmf)
+        steps_g = [_step(sample_h=g["sample_h"], vmode=1 if g["sample_v"] else 0, clamp=True) for _ in range(int(g["n_steps"]))]
+        steps_g.append(_step(clamp=False))                                          # rbm.py:400
+        mu, eta0 = self._mu()
+        steps_n = self._nmf_steps(n["n_steps"], n["T0"], n["T1"], n["sigma0"], n["sharpen_last"], n["T_cold_plus"], eta0 if mu is not None else 0.0)
+        a = {"v_known": self._in(g["v_known"]), "mask": self._in(g["known_mask"]), "steps": steps_g}
+        b = {"v_known": self._in(n["v_known"]), "mask": self._in(n["known_mask"]), "steps": steps_n, "mu": mu}
+        return eng.chain_pair(self, a, b, self._rng(a["v_known"].size(0)))
+
     # ---- clamped CD (rbm.py:402-483) -------------------------------------------------------------
     @torch.no_grad()
     def train_epoch_clamped(

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_sizes():
     lib = native.lib()
-    assert lib.imdbn_version() == native.ABI_VERSION == 3      # include/imdbn_engine.h IMDBN_ABI_VERSION
+    assert lib.imdbn_version() == native.ABI_VERSION == 4      # include/imdbn_engine.h IMDBN_ABI_VERSION
     assert lib.imdbn_ws_bytes(10000, 1500, 64) > 0
     assert lib.imdbn_ws_bytes(10000, 1500, 64) <= 128 << 20        # scratch stays small next to 288 GB
     assert lib.imdbn_ws_bytes(0, 10, 1) == 0

@@ -196,3 +196,42 @@ def test_streaming_k1_for_real_operands_equals_the_two_launch_path(V, H, B, _nat
     assert_close(P.N(b), P.N(ref), 2e-6, "two-launch path vs float64")
     xu = x.clone()                                  # untagged: per-item choice, all items real -> the same numbers
     assert torch.equal(r.forward(xu), a)
+
+
+@pytest.mark.parametrize("B,steps", [(64, 12), (256, 50), (37, 5)])
+def test_chain_pair_equals_the_two_chains_bit_for_bit(B, steps, _native):
+    """iMDBN._cross_reconstruct's IMG->TXT and TXT->IMG chains as ONE engine call (imdbn_rbm_chain_pair: both chains in one launch
+    of the row-parallel chain kernel) against the two calls of the reference order (imdbn.py:424-449): same draws, same bits."""
+    from imdbn import engine as E
+    from imdbn.models import RBM
+    eng = _native
+    g = np.random.Generator(np.random.PCG64(B))
+    Dz, K, H = 500, 32, 256
+    V = Dz + K
+    r = RBM(V, H, 0.04, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=[(Dz, V)]).to(DEV)
+    r.vis_bias.data.copy_(P.T((g.standard_normal(V, dtype=F32) * F32(0.3)), DEV))
+    z = P.T(g.random((B, Dz), dtype=F32), DEV)
+    y = torch.eye(K, device=DEV)[torch.from_numpy(g.integers(0, K, B)).to(DEV)]
+    vk = torch.zeros(B, V, device=DEV); km = torch.zeros_like(vk); vk[:, :Dz] = z; km[:, :Dz] = 1
+    vy = torch.zeros(B, V, device=DEV); ky = torch.zeros_like(vy); vy[:, Dz:] = y; ky[:, Dz:] = 1
+    mu = P.T(g.random((B, Dz), dtype=F32), DEV)
+    gibbs = dict(v_known=vk, known_mask=km, n_steps=steps, sample_h=False, sample_v=False)
+    nmf = dict(v_known=vy, known_mask=ky, n_steps=steps, T0=3.0, T1=1.0, sigma0=0.9, hot_frac=0.7, sharpen_last=3, T_cold_plus=0.9)
+    r._mu_pull = {"mu_k": mu, "eta0": 0.15}
+    with E.use_rng(E.PhiloxRng(seed=17)) as rng:
+        a1, b1 = r._chain_pair(gibbs, nmf)
+        used = rng.offset
+    with E.use_rng(E.PhiloxRng(seed=17)) as rng:
+        r._mu_pull = None
+        a2 = r.conditional_gibbs(**gibbs)
+        r._mu_pull = {"mu_k": mu, "eta0": 0.15}
+        b2 = r.noisy_meanfield_annealed(**nmf)
+        assert rng.offset == used
+    eng.set_option("no_chain_pair", 1)
+    try:
+        with E.use_rng(E.PhiloxRng(seed=17)):
+            a3, b3 = r._chain_pair(gibbs, nmf)
+    finally:
+        eng.set_option("no_chain_pair", 0)
+    assert torch.isfinite(a1).all() and torch.isfinite(b1).all()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2) and torch.equal(a1, a3) and torch.equal(b1, b3)

@@ -31,6 +31,47 @@ Z_CLAMP_EVERY = 50           # imdbn.py:600
 KBUF = 5                     # imdbn.py:452
 
 
+class _MetricsOverlap:
+    """train_joint's metrics pass on a second stream (see iMDBN.train_joint).  Two snapshots of the joint RBM alternate, so the main
+    stream never waits for the metrics of the batch before; it waits (normally: not at all) for those of two batches before."""
+
+    def __init__(self, model):
+        self.m = model
+        jr = model.joint_rbm
+        dev = jr.W.device
+        self.main = torch.cuda.current_stream(dev)
+        self.side = torch.cuda.Stream(dev)
+        self.snaps = []
+        with torch.random.fork_rng(devices=[dev]):             # (the constructor draws initial weights: leave torch's generators as they were)
+            for _ in range(2):
+                r = RBM(jr.num_visible, jr.num_hidden, jr.lr, jr.weight_decay, jr.momentum, dynamic_lr=jr.dynamic_lr,
+                        final_momentum=jr.final_momentum, softmax_groups=list(jr.softmax_groups)).to(dev)
+                self.snaps.append(r)
+        self.done = [None, None]
+        self.n = 0
+
+    def submit(self, acc, z_img, y, img):
+        k = self.n & 1
+        self.n += 1
+        jr, snap = self.m.joint_rbm, self.snaps[k]
+        if self.done[k] is not None:
+            self.main.wait_event(self.done[k])                 # the metrics that read this snapshot two batches ago are through
+        snap.W.data.copy_(jr.W.data); snap.hid_bias.data.copy_(jr.hid_bias.data); snap.vis_bias.data.copy_(jr.vis_bias.data)
+        ready = torch.cuda.Event()
+        ready.record(self.main)
+        for t in (acc, z_img, y, img):
+            t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            self.m._batch_metrics(acc, snap, z_img, y, img)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.done[k] = ev
+
+    def join(self):
+        self.main.wait_stream(self.side)
+
+
 class iMDBN(nn.Module):
     def __init__(
         self,
@@ -221,7 +262,7 @@ class iMDBN(nn.Module):
     # ---- cross-modal inference (imdbn.py:386-488) -------------------------------------------------
     @torch.no_grad()
     def _cross_reconstruct(self, z_img: torch.Tensor, y_onehot: torch.Tensor,
-                           steps: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                           steps: Optional[int] = None, _rbm: Optional[RBM] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Returns (img_from_txt [B,D], p_y_given_img [B,K]).
 
         The reference's best-of-K refinement is inert (RBM has no ``free_energy``; every candidate
@@ -233,7 +274,7 @@ class iMDBN(nn.Module):
             steps = self.cross_steps
         B, Dz, K = z_img.size(0), self.Dz_img, self.num_labels
         V = Dz + K
-        jr = self.joint_rbm
+        jr = self.joint_rbm if _rbm is None else _rbm       # (_rbm: train_joint's snapshot of the joint RBM, see _metrics_overlap)
         # IMG -> TXT (:419-427) and TXT -> IMG with mu-pull (:430-449).  The reference runs the two chains one after the other; they
         # share nothing but the joint RBM's read-only weights, so they go to the engine as one call (RBM._chain_pair: side by side
         # in one launch, same draws in the same order, same results)
@@ -259,7 +300,7 @@ class iMDBN(nn.Module):
         p_y_given_img = v_img2txt[:, Dz:]
         km = km_y
         if getattr(self, "live_best_of_k", False):
-            v_chain = self._best_of_k(v_chain, km, max(1, int(getattr(self, "best_of_k", KBUF))))[0]
+            v_chain = self._best_of_k(v_chain, km, max(1, int(getattr(self, "best_of_k", KBUF))), jr)[0]
         else:
             # dead refinement passes (:460-474): each would draw one U[B,V] at its chain init (rbm.py:333)
             _E.get_engine(jr.W.data).skip_draws(_E.get_rng(), [("u", V)] * (KBUF - 1), B)
@@ -270,11 +311,11 @@ class iMDBN(nn.Module):
         return self.image_idbn.decode(z_from_y), p_y_given_img
 
     @torch.no_grad()
-    def _best_of_k(self, v_chain: torch.Tensor, km: torch.Tensor, K: int):
+    def _best_of_k(self, v_chain: torch.Tensor, km: torch.Tensor, K: int, _rbm: Optional[RBM] = None):
         """Live version of imdbn.py:451-474: K-1 one-step refinements (T=0.9, no noise), free energy of every
         candidate, per-row argmin, device-side gather (the reference gathers with a Python loop over rows).
         Returns (v_pick [B,V], candidates [K,B,V], energies [K,B])."""
-        jr = self.joint_rbm
+        jr = self.joint_rbm if _rbm is None else _rbm
         cands, energies = [v_chain], [jr.free_energy(v_chain)]
         for _ in range(K - 1):
             v_last = jr.noisy_meanfield_annealed(v_known=cands[-1], known_mask=km, n_steps=1, T0=0.9, T1=0.9,
@@ -315,10 +356,15 @@ class iMDBN(nn.Module):
         self.init_joint_bias_from_data(n_batches=10)
         jr = self.joint_rbm
         self.joint_history = []
+        # The per-batch metrics (:615-639) only READ the model: `_cross_reconstruct` -- two 50-step chains and a decode, more device time
+        # than the batch's updates -- runs on a second stream against a snapshot of the joint RBM (0.55 MB) while the main stream
+        # goes on with the next batch's updates, which occupy a fraction of the chip.  Same calls, same draws in the same order, same
+        # numbers; one event each way per batch.  JOINT_METRICS_OVERLAP=False runs it in line.
+        ov = _MetricsOverlap(self) if (bool(self.params.get("JOINT_METRICS_OVERLAP", True)) and jr.W.is_cuda) else None
         for epoch in range(int(epochs)):
             cd_losses = []
             acc = torch.zeros(5, device=self.device, dtype=torch.float64)   # n, top1, top3, ce_sum, mse_sum
-            npix = None
+            npix, n_rows = None, 0
             for b_idx, (img, y) in enumerate(batches(self.dataloader)):
                 img = rows_on_device(img, self.device)
                 y = y.to(self.device).float()
@@ -347,19 +393,15 @@ class iMDBN(nn.Module):
                         jr.train_epoch_clamped(vk, km, epoch, epochs, CD=1, cond_init_steps=aux_cond_steps,
                                                sample_h=False, sample_v=False, reclamp_negative=False,
                                                aux_lr_mult=0.3, use_noisy_init=True)
-                with torch.no_grad():                                                # :615-639
-                    img_from_txt, p_y = self._cross_reconstruct(z_img, y, steps=self.cross_steps)
-                    gt = y.argmax(dim=1)
-                    pred = p_y.argmax(dim=1)
-                    topk_idx = p_y.topk(k=min(3, p_y.size(1)), dim=1).indices
-                    ce = F.binary_cross_entropy(p_y.clamp(1e-6, 1 - 1e-6),
-                                                F.one_hot(gt, num_classes=p_y.size(1)).float(), reduction="sum")
-                    mse = F.mse_loss(img_from_txt.view_as(img), img, reduction="sum")
-                    npix = img.size(1)
-                    acc += torch.stack([torch.tensor(float(B), device=self.device, dtype=torch.float64),
-                                        (pred == gt).sum().double(),
-                                        (topk_idx == gt.unsqueeze(1)).any(dim=1).sum().double(),
-                                        ce.double(), mse.double()])
+                npix = img.size(1)
+                n_rows += B
+                if ov is not None:
+                    ov.submit(acc, z_img, y, img)
+                else:
+                    self._batch_metrics(acc, self.joint_rbm, z_img, y, img)
+            if ov is not None:
+                ov.join()
+            acc[0] = float(n_rows)
             if _E.dp.active():                      # each rank accumulated its shard: sums over rows
                 _E.dp.all_reduce_sum(acc)
             a = acc.cpu()
@@ -376,6 +418,22 @@ class iMDBN(nn.Module):
                                     "cross_modality/text_ce": rec["text_ce"], "cross_modality/image_mse": rec["image_mse"],
                                     "epoch": epoch})
         print("[iMDBN] joint training finished.")
+
+    @torch.no_grad()
+    def _batch_metrics(self, acc, jr, z_img, y, img):
+        """imdbn.py:615-639: the online cross-modal metrics of one batch, accumulated on the device."""
+        img_from_txt, p_y = self._cross_reconstruct(z_img, y, steps=self.cross_steps, _rbm=jr)
+        gt = y.argmax(dim=1)
+        pred = p_y.argmax(dim=1)
+        topk_idx = p_y.topk(k=min(3, p_y.size(1)), dim=1).indices
+        ce = F.binary_cross_entropy(p_y.clamp(1e-6, 1 - 1e-6),
+                                    F.one_hot(gt, num_classes=p_y.size(1)).float(), reduction="sum")
+        mse = F.mse_loss(img_from_txt.view_as(img), img, reduction="sum")
+        # (the row count is added on the host at the end of the epoch: a `torch.tensor(B, device=...)` per batch is a blocking
+        #  host-to-device copy -- it alone cost 1.9 ms per batch and serialised the two streams)
+        acc[1:] += torch.stack([(pred == gt).sum().double(),
+                                (topk_idx == gt.unsqueeze(1)).any(dim=1).sum().double(),
+                                ce.double(), mse.double()])
 
     # ---- persistence (imdbn.py:815-934, SURVEY.md Appendix C) -------------------------------------
     def save_model(self, path: str):

@@ -235,3 +235,38 @@ def test_chain_pair_equals_the_two_chains_bit_for_bit(B, steps, _native):
         eng.set_option("no_chain_pair", 0)
     assert torch.isfinite(a1).all() and torch.isfinite(b1).all()
     assert torch.equal(a1, a2) and torch.equal(b1, b2) and torch.equal(a1, a3) and torch.equal(b1, b3)
+
+
+def test_train_joint_metrics_on_a_second_stream_equal_the_inline_pass(tmp_path):
+    """iMDBN.train_joint with its per-batch metrics (_cross_reconstruct, imdbn.py:615-639) overlapped on a second stream against a
+    snapshot of the joint RBM == the same loop with the metrics in line: weights, class means and every metric, bit for bit
+    (the draws are assigned on the host in program order either way)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from imdbn import engine as E
+    from imdbn.models import iMDBN
+    g = np.random.Generator(np.random.PCG64(11))
+    K, B, NB = 8, 16, 5
+    yi = g.integers(0, K, B * NB)
+    proto = (g.random((K, 1300), dtype=F32) > 0.7).astype(F32)
+    X = np.abs(proto[yi] - (g.random((B * NB, 1300), dtype=F32) > 0.9).astype(F32)).astype(F32)
+    Y = np.eye(K, dtype=F32)[yi]
+    dl = DataLoader(TensorDataset(torch.from_numpy(X).to(DEV), torch.from_numpy(Y).to(DEV)), batch_size=B, shuffle=False)
+    out = []
+    for overlap in (True, False):
+        params = {"LEARNING_RATE": 0.1, "WEIGHT_PENALTY": 1e-4, "INIT_MOMENTUM": 0.5, "FINAL_MOMENTUM": 0.95, "LEARNING_RATE_DYNAMIC": True,
+                  "CD": 1, "JOINT_LEARNING_RATE": 0.04, "JOINT_CD": 1, "JOINT_AUX_COND_STEPS": 12, "CROSS_GIBBS_STEPS": 9,
+                  "JOINT_METRICS_OVERLAP": overlap}
+        torch.manual_seed(5)
+        m = iMDBN([1300, 200, 60], 32, params=params, dataloader=dl, val_loader=dl, device=torch.device(DEV), num_labels=K)
+        with E.use_rng(E.PhiloxRng(seed=8)):
+            m.image_idbn.train(1)
+            m.train_joint(10)                    # 8 warm-up epochs + 2 main ones
+        torch.cuda.synchronize()
+        out.append(m)
+    a, b = out
+    _same(a.joint_rbm, b.joint_rbm, "joint RBM, overlapped vs inline metrics")
+    assert torch.equal(a.z_class_mean, b.z_class_mean)
+    for ha, hb in zip(a.joint_history, b.joint_history):
+        for k in ("n", "text_top1", "text_top3", "text_ce", "image_mse", "cd_loss"):
+            assert ha[k] == hb[k], (k, ha[k], hb[k])
+    assert np.isfinite([h["text_ce"] for h in a.joint_history]).all() and a.joint_history[-1]["n"] == B * NB

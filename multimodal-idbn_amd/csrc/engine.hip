@@ -229,7 +229,7 @@ Layout make_layout(int V, int H, int B, char* base) {
     {   // k1_stream: ~one block per CU; a K slice is a multiple of 64 rows and at most K1S_MAX_KCHUNK (its bits sit in LDS)
         L.k1s_tiles = cdiv(H, 32);
         int ks = g_k1s_ks > 0 ? g_k1s_ks : std::max(1, (int)((double)cu_count() / (double)(L.k1s_tiles * mb) + 0.5));
-        ks = std::min(ks, cdiv(L.Vpad, 64));
+        ks = std::min(ks, std::max(1, L.Vpad / 192));      // at least three K16 steps per wave and slice (1500 <-> 500: 8 slices of 192 rows, 45.5 us per update against 47.9 with 12 of 128)
         ks = std::max(ks, cdiv(L.Vpad, K1S_MAX_KCHUNK));
         L.k1s_kchunk = rup(cdiv(L.Vpad, ks), 64);
         L.k1s_ks = cdiv(L.Vpad, L.k1s_kchunk);
@@ -469,7 +469,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         if (want_hbits && !g_no_bits) f.op.rm = nullptr, f.rm_src = 0;      // the fused K2 reads the bit plane, nobody reads the bf16 form
         // 80 KB at the headline shape: two workgroups per CU (the bit-plane kernel carries the next batch's preparation blocks)
         a.region = k1s_bits ? K1S_RING : K1S_REGION_REAL;
-        const size_t lds = (size_t)4 * a.region + (size_t)8 * a.kchunk + (k1s_bits ? (next ? 0 : g_k1s_lds_pad) : K1S_LDS_EXTRA);
+        const size_t lds = (size_t)K1S_WAVES * a.region + (size_t)8 * a.kchunk + (k1s_bits ? (next ? 0 : g_k1s_lds_pad) : K1S_LDS_EXTRA);
         f.lean = lean_ok(f);
         // + block rows that prepare the next batch (one 64-column item each, or a few)
         PrepArgs pz;
@@ -482,8 +482,8 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         hipError_t le = hipSuccess;
 #define LAUNCH_K1S(NWV, NAV, GEV, RV) do { \
         static bool attr = false; \
-        if (!attr) { le = hipFuncSetAttribute((const void*)k1_stream<NWV, NAV, GEV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * K1S_REGION_REAL + 8 * K1S_MAX_KCHUNK + K1S_LDS_EXTRA); attr = true; } \
-        if (le == hipSuccess) hipLaunchKernelGGL((k1_stream<NWV, NAV, GEV, RV>), grid, dim3(256), lds, c.s, a, f, pa); } while (0)
+        if (!attr) { le = hipFuncSetAttribute((const void*)k1_stream<NWV, NAV, GEV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, K1S_WAVES * K1S_REGION_REAL + 8 * K1S_MAX_KCHUNK + K1S_LDS_EXTRA); attr = true; } \
+        if (le == hipSuccess) hipLaunchKernelGGL((k1_stream<NWV, NAV, GEV, RV>), grid, dim3(64 * K1S_WAVES), lds, c.s, a, f, pa); } while (0)
 #define LAUNCH_K1S_G(NWV, NAV, RV) do { if (f.lean) LAUNCH_K1S(NWV, NAV, false, RV); else LAUNCH_K1S(NWV, NAV, true, RV); } while (0)
         // (one instantiation per case: code that a launch does not run -- the general epilogue, the preparation blocks, the loop over
         //  bf16 terms -- still costs it time)

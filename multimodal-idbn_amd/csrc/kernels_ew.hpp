@@ -657,38 +657,46 @@ __global__ __launch_bounds__(256) void prep_operand(const PrepArgs a) {
 // third resident block per CU of the fused K2 (read-only stream, 23 us) the same work is done a few us into the launch.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// the 16 values of this thread (column c of tile tx, rows 16 kq .. + 15 of chunk mb): requested here, used by prep_item_process
-__device__ __forceinline__ void prep_item_load(const PrepArgs& a, int tx, int mb, float (&v)[16]) {
+// RPT rows per thread: 16 (blocks of 256 threads: four waves x two 8-row groups) or 8 (blocks of 512 threads: eight waves x one group)
+// the RPT values of this thread (column c of tile tx, rows RPT kq .. + RPT - 1 of chunk mb): requested here, used by prep_item_process
+template <int RPT>
+__device__ __forceinline__ void prep_item_load(const PrepArgs& a, int tx, int mb, float (&v)[RPT]) {
     const int c = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int cc = min(tx * 64 + c, a.N - 1);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = a.in[(int64_t)min(mb * 64 + 16 * kq + i, a.B - 1) * a.ld + cc];
+    for (int i = 0; i < RPT; ++i) v[i] = a.in[(int64_t)min(mb * 64 + RPT * kq + i, a.B - 1) * a.ld + cc];
 }
 
-__device__ __forceinline__ void prep_item_process(const PrepArgs& a, int tx, int mb, const float (&v)[16], bf16_t* rmst) {
+template <int RPT>
+__device__ __forceinline__ void prep_item_process(const PrepArgs& a, int tx, int mb, const float (&v)[RPT], bf16_t* rmst) {
+    static_assert(RPT == 16 || RPT == 8, "rows per thread");
+    constexpr int NWV = 64 / RPT;                    // waves of the block
     const int c = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int ntx = (max(a.N, a.op.ldrm) + 63) / 64;
     const int col = tx * 64 + c;
     const RmStage stg{rmst, 4, 64, tx * 64, mb * 64};
-    // adaptive: the item's forms follow its content (block-wide OR of "some value is neither 0 nor 1"; the four words sit
+    // adaptive: the item's forms follow its content (block-wide OR of "some value is neither 0 nor 1"; the words sit
     // behind the 24 KB stage, the caller's barrier after the item protects their reuse)
     OperandOut op = a.op;
     if (a.adaptive) {
         bool nb = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float x = (col < a.N && mb * 64 + 16 * kq + i < a.B) ? v[i] : 0.f;
+        for (int i = 0; i < RPT; ++i) {
+            const float x = (col < a.N && mb * 64 + RPT * kq + i < a.B) ? v[i] : 0.f;
             nb |= (x != 0.f && x != 1.0f);
         }
         int* sw = reinterpret_cast<int*>(rmst + 3 * 4 * 64 * 16);
         const bool anyb = __any(nb ? 1 : 0) != 0;
         if (c == 0) sw[kq] = anyb ? 1 : 0;
         lds_barrier();
-        if (!(sw[0] | sw[1] | sw[2] | sw[3])) { op.rm = nullptr; op.rm_terms = 0; op.tr_terms = 1; }
+        int any_item = 0;
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) any_item |= sw[q];
+        if (!any_item) { op.rm = nullptr; op.rm_terms = 0; op.tr_terms = 1; }
     }
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const int b0 = mb * 64 + 16 * kq + 8 * hf, by = b0 >> 3;
+    for (int hf = 0; hf < RPT / 8; ++hf) {
+        const int b0 = mb * 64 + RPT * kq + 8 * hf, by = b0 >> 3;
         float x[8];
         bool inexact = false, nonbin = false;
 #pragma unroll
@@ -711,10 +719,11 @@ __device__ __forceinline__ void prep_item_process(const PrepArgs& a, int tx, int
     }
 }
 
+template <int RPT = 16>
 __device__ __forceinline__ void prep_item_body(const PrepArgs& a, int tx, int mb, bf16_t* rmst) {
-    float v[16];
-    prep_item_load(a, tx, mb, v);
-    prep_item_process(a, tx, mb, v, rmst);
+    float v[RPT];
+    prep_item_load<RPT>(a, tx, mb, v);
+    prep_item_process<RPT>(a, tx, mb, v, rmst);
 }
 
 // Free energy of visible configurations (imdbn/utils/energy_utils.py:19-28):

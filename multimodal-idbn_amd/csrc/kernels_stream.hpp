@@ -32,12 +32,16 @@ __device__ __forceinline__ void dma4(const void* g, uint32_t lds_off) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
-constexpr int K1S_D = 4;                          // ring slots per wave; a slot = 2 K16 steps = 4 instructions = 32 rows x 128 B
-constexpr int K1S_RING = K1S_D * 4 * 1024;        // 16 KB per wave
-constexpr int K1S_REGION_REAL = 32 * 1024;        // per-wave LDS of the kernels that can read bf16 terms: weight ring (6 K16 steps, 12 KB) + A ring (3 steps x 2 NA KB)
-constexpr int K1S_WSTEPS = 6, K1S_ASTEPS = 3;     // ring depths (K16 steps) of that loop
-constexpr int K1S_MAX_KCHUNK = 3584;              // LDS: rings + 8 B per K row of activation bits (4 x 32 KB + 28 KB + K1S_LDS_EXTRA <= 160 KB)
-constexpr int K1S_LDS_EXTRA = 64 + 2048;          // behind the bits (adaptive operands): 16 mask / scratch words, 2 x 256 exactness-map entries
+constexpr int K1S_WAVES = 8;                      // waves per block = two per SIMD.  With one wave per SIMD (rounds 2 / 3a) the K loop was bound by
+                                                  // instruction issue, not memory: per K16 step ~85 dependent VALU instructions (fp32 -> 3 bf16 terms, bits ->
+                                                  // fragments), the LDS latency of the fragment reads and 6 MFMAs back to back took ~870 cycles for 2 KB per wave
+                                                  // (4.9 TB/s chip-wide against 6.4 for the bare LDS-DMA stream); two waves hide each other's latencies
+constexpr int K1S_D = 2;                          // ring slots per wave; a slot = 2 K16 steps = 4 instructions = 32 rows x 128 B
+constexpr int K1S_RING = K1S_D * 4 * 1024;        // 8 KB per wave (64 KB per block in flight, as with 4 waves x 16 KB)
+constexpr int K1S_REGION_REAL = 16 * 1024;        // per-wave LDS of the kernels that can read bf16 terms: weight ring (2 K16 steps, 4 KB) + A ring (2 steps x 2 NA KB)
+constexpr int K1S_WSTEPS = 2, K1S_ASTEPS = 2;     // ring depths (K16 steps) of that loop
+constexpr int K1S_MAX_KCHUNK = 3520;              // LDS: rings + 8 B per K row of activation bits (8 x 16 KB + 27.5 KB + K1S_LDS_EXTRA <= 160 KB)
+constexpr int K1S_LDS_EXTRA = 64 + 4096;          // behind the bits (adaptive operands): 16 mask / scratch words, 2 x 512 exactness-map entries
 
 // How the activation operand of k1_stream is read (K1sArgs::amode).  Whatever the mode, a K16 step multiplies the same
 // fragments in the same order -- for a 0/1 value the bit plane and the first bf16 term are the same number and the further
@@ -62,11 +66,10 @@ struct K1sArgs {
     // the update kernel decides 1 or 3 planes per block over `fix_span` items -- where a span mixes both kinds, the binary items'
     // planes 1, 2 are zeroed here (what a three-term split of 0/1 values is).  Cold path; nullptr = off.
     bf16_t* fix_tr; int64_t fix_ts; int fix_span, fix_ranges;
-
 };
 
-// `next` / block rows >= a.ks: the launch can carry the preparation of the NEXT batch of the training loop (prep_item_body:
-// imdbn_cd_opts.next_data) as extra workgroups.  This kernel is a read-only stream with one workgroup per CU, 131 registers
+// `next` / block rows >= a.ks (RIDER): the launch can carry the preparation of the NEXT batch of the training loop
+// (prep_item_body: imdbn_cd_opts.next_data) as extra workgroups.  This kernel is a read-only stream with one workgroup per CU
 // and exactly half of a CU's LDS (64 KB of rings + 16 KB of bits at the headline shape): a second workgroup fits beside each
 // streaming one, so the extra blocks start at once and are gone a few us into the launch.  (The update kernel's idle CUs were
 // tried first: under its read + write stream the same work took 25-45 us longer than the kernel itself.)
@@ -77,19 +80,18 @@ struct K1sArgs {
 // in inline asm were tried: the compiler moves their destination registers around before the wait that makes them valid; plain
 // loads make it wait vmcnt(0) at every use beside LDS-DMA).  A block whose K slice holds only 0/1 items runs the bit-plane loop.
 // GE = the general epilogue (temperature, noise, clamp, fp32 outputs, K16-blocked form ...) is compiled in; the launches of a
-// CD pass only need the lean one (FinishArgs::lean), and a kernel without the general epilogue's ~25 000 instructions (and, for
-// NA > 0, without the preparation blocks) measurably starts and runs faster: code size is not free here.
-// RIDER = the launch may carry preparation blocks of the next batch (bit-plane instantiation only).
+// CD pass only need the lean one (FinishArgs::lean), and a kernel without the general epilogue's ~25 000 instructions (and
+// without the preparation blocks) measurably starts and runs faster: code size is not free here.
 template <int NW, int NA, bool GE, bool RIDER>
-__global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const FinishArgs fa, const PrepArgs next) {
+__global__ __launch_bounds__(64 * K1S_WAVES, (RIDER && !GE) ? 4 : 2) void k1_stream(const K1sArgs a, const FinishArgs fa, const PrepArgs next) {
     constexpr bool REAL = NA > 0;
     static_assert(!(RIDER && REAL), "preparation blocks ride on the bit-plane instantiation");
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 rings][activation bits][mask words]; no static LDS (keeps the base 16-B aligned)
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [8 rings][activation bits][mask words, map entries]; no static LDS (keeps the base 16-B aligned)
     if (RIDER && (int)blockIdx.y >= a.ks) {
         const int nworkers = (gridDim.y - a.ks) * gridDim.x, wid = (blockIdx.y - a.ks) * gridDim.x + blockIdx.x;
         const int ntx = (max(next.N, next.op.ldrm) + 63) / 64;
         for (int it = wid; it < ntx; it += nworkers) {
-            prep_item_body(next, it, blockIdx.z, reinterpret_cast<bf16_t*>(smem));
+            prep_item_body<8>(next, it, blockIdx.z, reinterpret_cast<bf16_t*>(smem));      // eight waves x one 8-row group each
             if (next.op.rm || next.adaptive) lds_barrier();
         }
         return;
@@ -99,37 +101,38 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     const int n0 = tile * 32, mb = z * 64;
     const int k0 = sl * a.kchunk;
     const int k_end = min(k0 + a.kchunk, (a.K + 15) / 16 * 16);
-    const int nsteps = (k_end - k0) / 16;                 // K16 steps of this slice; wave w takes steps w, w + 4, ...
-    const int my_steps = (nsteps - w + 3) / 4;
+    const int nsteps = (k_end - k0) / 16;                 // K16 steps of this slice; wave w takes steps w, w + 8, ...
+    const int my_steps = (nsteps - w + K1S_WAVES - 1) / K1S_WAVES;
     const int n_slots = (my_steps + 1) / 2;
     const int REGION = a.region;                          // LDS per wave
     char* ring = smem + w * REGION;
-    const uint8_t* abl = reinterpret_cast<const uint8_t*>(smem + 4 * REGION);      // [kchunk/8][64] bytes
-    uint32_t* smask = reinterpret_cast<uint32_t*>(smem + 4 * REGION + 8 * a.kchunk);      // [4 waves][4 words]
+    const uint8_t* abl = reinterpret_cast<const uint8_t*>(smem + K1S_WAVES * REGION);      // [kchunk/8][64] bytes
+    uint32_t* smask = reinterpret_cast<uint32_t*>(smem + K1S_WAVES * REGION + 8 * a.kchunk);      // 16 words
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)ring);
-    const uint32_t abl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem) + 4 * REGION;
+    const uint32_t abl_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem) + K1S_WAVES * REGION;
 
     const bool st = (fa.dbg & 64) != 0;                   // tuning aid: per-block timeline (tools/stamps_probe.py)
     const int sblk = (z * gridDim.y + sl) * ntiles + tile;
     stamp(st, sblk, 0);
     const int cb0 = k0 / 64, cb1 = min((k_end + 63) / 64, a.ncb), wd = cb1 - cb0;      // 64-column items of this slice
     // ---- ADAPTIVE (host: at most 32 items per slice, at most 256 map entries per span of the update kernel): thread (p = tid >> 5,
-    // j = tid & 31) fetches the exactness-map entry of row group p of item j, and entry `tid` of the span the update kernel ORs for
-    // one of its blocks.  The two loads are requested BEHIND the bits and the first ring slots and looked at after the bit-plane
-    // loop: a batch of 0/1 images -- the case that matters -- runs exactly the instruction stream of the bit-plane kernel, and a
-    // slice that turns out to hold other values is done again from its bf16 terms.  They are LDS-DMA like everything else in
-    // flight here (no destination registers: register loads written in inline asm were tried -- the compiler copies their
-    // destinations around before the wait that makes them valid -- and its own loads it waits for with vmcnt(0)).
+    // j = tid & 31), tid < 256, fetches the exactness-map entry of row group p of item j, and entry `tid` of the span the update
+    // kernel ORs for one of its blocks (waves 4-7 fetch the same again: every wave has the same two loads in flight).  The two
+    // loads are requested BEHIND the bits and the first ring slots and looked at after the bit-plane loop: a batch of 0/1 images --
+    // the case that matters -- runs exactly the instruction stream of the bit-plane kernel, and a slice that turns out to hold
+    // other values is done again from its bf16 terms.  They are LDS-DMA like everything else in flight here (no destination
+    // registers: register loads written in inline asm were tried -- the compiler copies their destinations around before the
+    // wait that makes them valid -- and its own loads it waits for with vmcnt(0)).
     const bool adaptive = REAL && a.amode == K1S_ADAPTIVE;
     const int fix_r = sl * ntiles + tile;
     const bool fixer = REAL && adaptive && a.fix_tr && z == 0 && fix_r < a.fix_ranges;
     constexpr int NF = 2;                                 // those loads, per wave
-    const uint32_t* sfl = smask + 16;                     // [256] entries of the slice's items, [256] of the span
-    // ---- activation bits of the slice -> LDS (16 byte-rows = 1 KB per instruction, dealt to the four waves)
+    const uint32_t* sfl = smask + 16;                     // [512] entries of the slice's items (twice), [512] of the span (twice)
+    // ---- activation bits of the slice -> LDS (16 byte-rows = 1 KB per instruction, dealt to the waves)
     const bool have_bits = !REAL || a.amode != K1S_REAL;
     if (have_bits) {
         const int nrows8 = a.kchunk / 8, last_row = (a.K + 63) / 64 * 8 - 1;
-        for (int q = w; q * 16 < nrows8; q += 4) {
+        for (int q = w; q * 16 < nrows8; q += K1S_WAVES) {
             const int br = min((k0 >> 3) + 16 * q + (l >> 2), last_row);
             dma16(a.abits + (int64_t)br * a.Bp + mb + 16 * (l & 3), abl_lds + q * 1024);
         }
@@ -142,41 +145,38 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
         for (int sub = 0; sub < 2; ++sub) {
             const int i = 2 * si + sub;
             if (i < my_steps) {                           // wave-uniform
-                const int krow = k0 + 16 * (4 * i + w) + (l >> 3);
+                const int krow = k0 + 16 * (K1S_WAVES * i + w) + (l >> 3);
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)      // (non-temporal loads were tried in round 3: K1 unchanged, the update kernel 2-5 us slower -- W leaves the cache;
+                                                  //  even the wave-uniform branch that selected them cost this loop 1.5 us: it is bound by instruction issue)
                     dma16(wsrc + (int64_t)min(krow + 8 * h, a.K - 1) * a.ldw, ring_lds + ((d * 2 + sub) * 2 + h) * 1024);
             }
         }
     };
-    // epilogue side inputs (bias, ...) of this thread's column x 8 rows: requested now (before the ring, so that the counted
-    // waits below still see the ring's instructions as the youngest), used by the tile's last arriver -- their first-touch
-    // latency would otherwise sit behind the split-K combine
+    // epilogue side inputs (bias, ...) of this thread's column x 8 rows (threads 0..255 run the epilogue): requested now (before
+    // the ring, so that the counted waits below still see the ring's instructions as the youngest), used by the tile's last
+    // arriver -- their first-touch latency would otherwise sit behind the split-K combine
     // (the true column also past N: the epilogue stores nothing there but the zeros of the K16-blocked form's padding columns
     //  [N, ldrm), which the next propagation multiplies with clamped, non-zero weights; 32-column tiles never overlap)
     const int ecol = n0 + (tid & 31);
     SideIn<8> side;
     SideLean sl8;
-    if (!GE || fa.lean) load_side_lean(fa, ecol, mb + 8 * (tid >> 5), sl8);
-    else if constexpr (GE) load_side<8>(fa, ecol, mb + 8 * (tid >> 5), side);
-    // the loop over bf16 terms works one K16 step at a time: weight ring of 6 steps (2 KB each) + A ring of 3 steps (2 NA KB)
+    if (!GE || fa.lean) load_side_lean(fa, ecol, mb + 8 * ((tid >> 5) & 7), sl8);
+    else if constexpr (GE) load_side<8>(fa, ecol, mb + 8 * ((tid >> 5) & 7), side);
+    // the loop over bf16 terms works one K16 step at a time: weight ring of 2 steps (2 KB each) + A ring of 2 steps (2 NA KB)
     constexpr int AOPS = 2 * NA;                              // LDS-DMA per A step (2 row halves x NA terms, 1 KB each)
     const int nkb = (a.K + 15) / 16;
     const uint32_t aring_lds = ring_lds + K1S_WSTEPS * 2048;
     const char* aring = ring + K1S_WSTEPS * 2048;
     const bf16_t* abase = a.arm + (int64_t)mb * 16 + 8 * l;   // lane l: 16 B at [row l >> 1][half l & 1] of a 32-row half
-    auto issue_w = [&](int i) __attribute__((always_inline)) {       // weight step i -> ring position i % 6
-        if (i < my_steps) {                                    // wave-uniform
-            const int krow = k0 + 16 * (4 * i + w) + (l >> 3);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                dma16(wsrc + (int64_t)min(krow + 8 * h, a.K - 1) * a.ldw, ring_lds + ((i % K1S_WSTEPS) * 2 + h) * 1024);
-        }
-    };
-    auto issue_a = [&](int i) __attribute__((always_inline)) {       // A step i -> ring position i % 3: [mt][term] KB
+    auto issue_wa = [&](int i) __attribute__((always_inline)) {      // step i: weights -> ring position i % 2, A fragments -> [i % 2][mt][term] KB
         if constexpr (REAL) {
-            if (i < my_steps) {
-                const int kb = min((k0 >> 4) + 4 * i + w, nkb - 1);
+            if (i < my_steps) {                                // wave-uniform
+                const int krow = k0 + 16 * (K1S_WAVES * i + w) + (l >> 3);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    dma16(wsrc + (int64_t)min(krow + 8 * h, a.K - 1) * a.ldw, ring_lds + ((i % K1S_WSTEPS) * 2 + h) * 1024);
+                const int kb = min((k0 >> 4) + K1S_WAVES * i + w, nkb - 1);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -185,25 +185,19 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             }
         }
     };
-    auto start_real = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < K1S_WSTEPS; ++i) issue_w(i);
-#pragma unroll
-        for (int i = 0; i < K1S_ASTEPS; ++i) issue_a(i);
-    };
     const bool known_real = REAL && a.amode == K1S_REAL;
     if (known_real) {
-        start_real();
+        issue_wa(0);
+        issue_wa(1);
     } else {
 #pragma unroll
         for (int d = 0; d < K1S_D; ++d) issue_slot(d, d);
-        // the bits (issued first) have landed once at most the ring's instructions are outstanding
         if (adaptive) {
             const int i0 = fixer ? fix_r * a.fix_span : 0, nitem = fixer ? min(a.fix_span, a.ncb - i0) : 1, ne = fixer ? nitem * a.P : 1;
-            const int ie = min(tid, ne - 1);
+            const int t8 = tid & 255, ie = min(t8, ne - 1);
             const uint32_t sfl_lds = abl_lds + 8 * a.kchunk + 64 + w * 256;
-            dma4(a.aflag + (int64_t)(z * 8 + (tid >> 5)) * a.ncb + min(cb0 + (tid & 31), a.ncb - 1), sfl_lds);
-            dma4(a.aflag + (int64_t)(ie / nitem) * a.ncb + i0 + (ie % nitem), sfl_lds + 1024);
+            dma4(a.aflag + (int64_t)(z * 8 + (t8 >> 5)) * a.ncb + min(cb0 + (tid & 31), a.ncb - 1), sfl_lds);
+            dma4(a.aflag + (int64_t)(ie / nitem) * a.ncb + i0 + (ie % nitem), sfl_lds + 2048);
         }
         // the bits (issued first) have landed once at most the ring's instructions (and the map loads behind them) are outstanding
         if (my_steps >= 2 * K1S_D) { if (adaptive) wait_vmcnt<4 * K1S_D + NF>(); else wait_vmcnt<4 * K1S_D>(); }
@@ -226,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(base + j * 128);
             uint4 bf[NW];
             make_w_frags<NW>(x, bf);
-            const int jstep = 4 * i + w;                      // K16 step inside the slice: bytes 2 jstep, 2 jstep + 1 of a batch row
+            const int jstep = K1S_WAVES * i + w;              // K16 step inside the slice: bytes 2 jstep, 2 jstep + 1 of a batch row
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const uint4 af = bits_to_frag(abl[(2 * jstep + kg) * 64 + 32 * mt + n]);
@@ -256,46 +250,41 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
     if constexpr (REAL) {
         if (adaptive) {
             // item j of the slice needs its bf16 terms when any of its 8 row groups holds a value that is neither 0 nor 1:
-            // lanes 0-31 / 32-63 of wave w hold row groups 2w / 2w + 1 of items 32 q + j
+            // lanes 0-31 / 32-63 of wave w < 4 hold row groups 2w / 2w + 1 of item j
             wait_vmcnt<0>();
-            const unsigned long long m = __ballot(((sfl[tid] & FLAG_NONBINARY) != 0u && (tid & 31) < wd) ? 1 : 0);
-            if (l == 0) smask[w] = (uint32_t)m | (uint32_t)(m >> 32);
+            const unsigned long long m = __ballot(((sfl[tid & 255] & FLAG_NONBINARY) != 0u && (tid & 31) < wd) ? 1 : 0);
+            if (l == 0 && w < 4) smask[w] = (uint32_t)m | (uint32_t)(m >> 32);
         }
     }
     if (!known_real) wait_vmcnt<0>();                     // (announced real values: the rings requested in the prologue stay in flight)
     stamp(st, sblk, 2);
-    __syncthreads();                                      // every wave is done with its ring (the area becomes red[4][64][32]); the mask words are complete
+    __syncthreads();                                      // every wave is done with its ring (the area becomes red[8][64][32]); the mask words are complete
     if constexpr (REAL) {
-        if (adaptive) {
-            mlo = __builtin_amdgcn_readfirstlane(smask[0] | smask[1] | smask[2] | smask[3]);      // items 0 .. 31 of the slice
-        }
+        if (adaptive) mlo = __builtin_amdgcn_readfirstlane(smask[0] | smask[1] | smask[2] | smask[3]);      // items 0 .. 31 of the slice
     }
     const bool real_loop = REAL && (known_real || mlo != 0u);
     if constexpr (REAL) if (real_loop) {
-        // ---- operands with bf16 terms, one K16 step at a time.  Issue order: prologue W0..W5, A0..A2; iteration i, after its
-        // MFMAs: A(i+3), W(i+6).  vmcnt retires in order, so before iteration i everything up to A(i) has landed once only the
-        // younger W(i+3) A(i+1) W(i+4) A(i+2) W(i+5) are outstanding.  (ADAPTIVE: the slice was first run as bit planes -- all waves
-        // are past that loop, the rings are free -- and is done again from scratch: the price of real values in a batch nobody
-        // announced.)
+        // ---- operands with bf16 terms, one K16 step at a time.  Issue order: prologue W0 A0 W1 A1; iteration i, after its MFMAs:
+        // W(i+2) A(i+2).  vmcnt retires in order, so before iteration i everything up to A(i) has landed once only the younger
+        // W(i+1) A(i+1) are outstanding.  (ADAPTIVE: the slice was first run as bit planes -- all waves are past that loop, the
+        // rings are free -- and is done again from scratch: the price of real values in a batch nobody announced.)
         if (!known_real) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-            start_real();
+            issue_wa(0);
+            issue_wa(1);
         }
         for (int i = 0; i < my_steps; ++i) {
-            // counted waits while everything younger was issued in full (W(i+5) exists)
-            if (i + 5 < my_steps) {
-                if (i >= 3) wait_vmcnt<2 * AOPS + 6>(); else if (i == 2) wait_vmcnt<2 * AOPS + 4>(); else if (i == 1) wait_vmcnt<2 * AOPS + 2>(); else wait_vmcnt<2 * AOPS>();
-            } else wait_vmcnt<0>();
+            if (i + 1 < my_steps) wait_vmcnt<2 + AOPS>(); else wait_vmcnt<0>();
             const char* base = ring + ((i % K1S_WSTEPS) * 2) * 1024 + (8 * kg) * 128 + 4 * n;
             float x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(base + j * 128);
             uint4 bf[NW];
             make_w_frags<NW>(x, bf);
-            const int jstep = 4 * i + w, item = jstep >> 2;
+            const int jstep = K1S_WAVES * i + w, item = jstep >> 2;
             const bool isbin = a.amode == K1S_ADAPTIVE && ((mlo >> (item & 31)) & 1u) == 0u;      // wave-uniform
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -317,8 +306,7 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the step's fragments are in registers: refill its ring places
             __builtin_amdgcn_sched_barrier(0);
-            issue_a(i + K1S_ASTEPS);
-            issue_w(i + K1S_WSTEPS);
+            issue_wa(i + 2);
         }
         wait_vmcnt<0>();
         __syncthreads();                                  // every wave is done with its rings
@@ -331,17 +319,19 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
             const bool wany = __any(v) != 0;                  // (all lanes: not inside the lane-0 branch)
             if (l == 0) smask[w] = wany ? 1u : 0u;
             __syncthreads();
-            const uint32_t r = smask[0] | smask[1] | smask[2] | smask[3];
+            uint32_t r = 0u;
+#pragma unroll
+            for (int ww = 0; ww < K1S_WAVES; ++ww) r |= smask[ww];
             __syncthreads();
             return r != 0u;
         };
-        if (fixer && block_or(sfl[256 + tid] & FLAG_INEXACT)) {
+        if (fixer && block_or(sfl[512 + (tid & 255)] & FLAG_INEXACT)) {
             const int i0 = fix_r * a.fix_span, nitem = min(a.fix_span, a.ncb - i0);
             for (int it = 0; it < nitem; ++it)
                 for (int zc = 0; zc < a.Bp / 64; ++zc) {
                     const int nb = (tid < 8) ? (a.aflag[(zc * 8 + tid) * a.ncb + i0 + it] & FLAG_NONBINARY) : 0;
                     if (block_or(nb)) continue;
-                    for (int i = tid; i < 2 * 64 * 8; i += 256) {
+                    for (int i = tid; i < 2 * 64 * 8; i += 64 * K1S_WAVES) {
                         const int pl = 1 + (i >> 9), c = (i >> 3) & 63, q = i & 7, col = (i0 + it) * 64 + c;
                         if (col < a.K) *reinterpret_cast<uint4*>(a.fix_tr + pl * a.fix_ts + (int64_t)col * a.Bp + zc * 64 + 8 * q) = make_uint4(0u, 0u, 0u, 0u);
                     }
@@ -349,28 +339,33 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
         }
     }
 
-    // ---- cross-wave sum (fixed order) -> this thread's 8 values: column n0 + c, batch rows mb + 8 oct .. + 7
+    // ---- cross-wave sum (fixed order) -> threads 0..255: column n0 + c, batch rows mb + 8 oct .. + 7
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) red[(w * 64 + mt * 32 + mfma_row(reg, l)) * 32 + n] = acc[mt][reg];
     __syncthreads();
+    if (tid >= 256) return;                               // the epilogue is the work of four waves (one column x 8 rows per thread)
+    auto sync4 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };      // the four waves left
     const int c = tid & 31, oct = tid >> 5;
     float xs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int o = (8 * oct + i) * 32 + c;
-        xs[i] = ((red[o] + red[2048 + o]) + red[2 * 2048 + o]) + red[3 * 2048 + o];
+        float t = red[o];
+#pragma unroll
+        for (int ww = 1; ww < K1S_WAVES; ++ww) t += red[ww * 2048 + o];
+        xs[i] = t;
     }
     // caller data that were promised to be 0/1 and are not: the bit plane does not describe them -> NaN, loudly
-    int* s_words = reinterpret_cast<int*>(smem + 2 * K1S_RING);        // scratch words behind red[] (the rings are free now)
+    int* s_words = reinterpret_cast<int*>(smem + K1S_WAVES * 8192);        // scratch words behind red[] (rings / bits are free now)
     if (a.amode == K1S_ASSERTED) {
         int bad = 0;
         for (int i = tid; i < wd * 8; i += 256) bad |= a.aflag[(z * 8 + i / wd) * a.ncb + cb0 + (i % wd)] & FLAG_NONBINARY;
-        if (l == 0) s_words[4 + w] = 0;
-        if (__any(bad) && l == 0) s_words[4 + w] = 1;
-        __syncthreads();
+        const bool wbad = __any(bad) != 0;
+        if (l == 0) s_words[4 + w] = wbad ? 1 : 0;
+        sync4();
         if (s_words[4] | s_words[5] | s_words[6] | s_words[7]) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) xs[i] = __uint_as_float(0x7FC00000u);
@@ -384,12 +379,11 @@ __global__ __launch_bounds__(256, 1) void k1_stream(const K1sArgs a, const Finis
         gu32* mine = (gu32*)(a.slabs + (((int64_t)z * a.ks + sl) * ntiles + tile) * 2048);
 #pragma unroll
         for (int i = 0; i < 8; ++i) __hip_atomic_store(mine + (8 * oct + i) * 32 + c, __float_as_uint(xs[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the barrier, the counter add comes after it
-        __syncthreads();
+        sync4();                                          // EVERY storing wave drains (vmcnt(0)) before the barrier, the counter add comes after it
         int* cnt = a.counters + z * ntiles + tile;
         int* s_last = s_words;
         if (tid == 0) *s_last = (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ks - 1) ? 1 : 0;
-        __syncthreads();
+        sync4();
         stamp(st, sblk, 4);
         if (!*s_last) return;
         if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch

@@ -74,10 +74,9 @@ def test_k3_counted_waits_match_the_emitted_prefetch_loads(functions):
 
 def _check_term_loop_counts(name, body, na):
     """k1_stream's loop over bf16 terms (kernels_stream.hpp): per K16 step 2 LDS-DMA of weights and 2 NA LDS-DMA of A fragments, issued
-    after the step's MFMAs as A(i+3), W(i+6); its counted wait leaves the younger W(i+3) A(i+1) W(i+4) A(i+2) W(i+5) in flight =
-    4 NA + 6 operations.  Checked in the emitted code: between two consecutive counted waits of the steady state lie exactly 2 NA + 2
+    after the step's MFMAs as W(i+2) A(i+2); its counted wait leaves the younger W(i+1) A(i+1) in flight = 2 NA + 2 operations.  Checked in the emitted code: between two consecutive counted waits of the steady state lie exactly 2 NA + 2
     LDS-DMA (one step's worth), and no register-destination load at all (the compiler would wait vmcnt(0) for it)."""
-    steady = 4 * na + 6
+    steady = 2 * na + 2
     in_asm, seen, dma, plain, counting = False, 0, 0, 0, False
     for l in body:
         if l.startswith(";;#ASMSTART"):
@@ -107,10 +106,10 @@ def test_streaming_kernels_have_no_scratch_and_only_the_planned_counts(functions
     for name, body in ks.items():
         na = int(re.search(r"k1_streamILi\dELi(\d)E", name).group(1))      # bf16 terms the kernel can read per element (0: bit planes only)
         counts = {n for _, n in _hand_waits(body)}
-        planned = {0, 12, 16}                                 # 0, 4 (D - 1), 4 D  (kernels_stream.hpp K1S_D = 4): the bit-plane loop
+        planned = {0, 4, 8}                                   # 0, 4 (D - 1), 4 D  (kernels_stream.hpp K1S_D = 2): the bit-plane loop
         if na:
-            planned |= {4 * na, 4 * na + 2, 4 * na + 4, 4 * na + 6}       # loop over bf16 terms: A(i+1) A(i+2) [+ W(i+3)] [+ W(i+4)] [+ W(i+5)] may stay in flight
-            planned |= {12 + 2, 16 + 2}                                   # bit-plane loop with the 2 exactness-map loads issued behind the first ring slots
+            planned |= {2 + 2 * na}                                       # loop over bf16 terms: W(i+1) A(i+1) may stay in flight
+            planned |= {4 + 2, 8 + 2}                                     # bit-plane loop with the 2 exactness-map loads issued behind the first ring slots
         assert counts <= planned, (name, counts)
         assert not any(l.startswith("scratch_") for l in body), f"{name} spills to scratch"
         if na:

@@ -32,6 +32,40 @@ __device__ __forceinline__ void dma4(const void* g, uint32_t lds_off) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
+// fp32 -> NW bf16 terms with round-to-nearest conversions (v_cvt_pk_bf16_f32: two values and the packing in ONE instruction):
+// hi = rne(w), r = w - hi (exact: <= 16 significant bits), mid = rne(r), lo = r - mid (exact in bf16: <= 8 bits), so hi + mid + lo
+// == w exactly, as with the truncation split of make_w_frags -- in ~36 instead of ~56 instructions per 8 weights, which matters in
+// k1_stream's issue-bound K loop.  (Other kernels keep the truncation split; the products are exact either way.)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+template <int NW>
+__device__ __forceinline__ void make_w_frags_rne(const float (&wv)[8], uint4 (&frag)[NW]) {
+    uint32_t h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = cvt_pk_bf16(wv[2 * j], wv[2 * j + 1]);
+    frag[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    if constexpr (NW == 3) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[2 * j] = wv[2 * j] - __uint_as_float(h[j] << 16);
+            r[2 * j + 1] = wv[2 * j + 1] - __uint_as_float(h[j] & 0xFFFF0000u);
+        }
+        uint32_t m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = cvt_pk_bf16(r[2 * j], r[2 * j + 1]);
+        frag[1] = make_uint4(m[0], m[1], m[2], m[3]);
+        uint32_t lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            lo[j] = cvt_pk_bf16(r[2 * j] - __uint_as_float(m[j] << 16), r[2 * j + 1] - __uint_as_float(m[j] & 0xFFFF0000u));
+        frag[2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
 constexpr int K1S_WAVES = 8;                      // waves per block = two per SIMD.  With one wave per SIMD (rounds 2 / 3a) the K loop was bound by
                                                   // instruction issue, not memory: per K16 step ~85 dependent VALU instructions (fp32 -> 3 bf16 terms, bits ->
                                                   // fragments), the LDS latency of the fragment reads and 6 MFMAs back to back took ~870 cycles for 2 KB per wave
@@ -213,17 +247,14 @@ __global__ __launch_bounds__(64 * K1S_WAVES, (RIDER && !GE) ? 4 : 2) void k1_str
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
     if (!known_real) {
-        auto compute = [&](int d, int sub, int i) __attribute__((always_inline)) {           // K16 step i of this wave, in ring slot d
-            const char* base = ring + ((d * 2 + sub) * 2) * 1024 + (8 * kg) * 128 + 4 * n;
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(base + j * 128);
+        // a slot = two K16 steps: the fragments of BOTH are requested from LDS before the first one's arithmetic (the second step's
+        // LDS latency hides under the first step's VALU / MFMA work; a partial last slot reads LDS garbage it does not use)
+        auto math = [&](const float (&x)[8], const uint32_t (&bb)[2], int) __attribute__((always_inline)) {
             uint4 bf[NW];
-            make_w_frags<NW>(x, bf);
-            const int jstep = K1S_WAVES * i + w;              // K16 step inside the slice: bytes 2 jstep, 2 jstep + 1 of a batch row
+            make_w_frags_rne<NW>(x, bf);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const uint4 af = bits_to_frag(abl[(2 * jstep + kg) * 64 + 32 * mt + n]);
+                const uint4 af = bits_to_frag(bb[mt]);
 #pragma unroll
                 for (int tw = 0; tw < NW; ++tw)
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af), as_frag(bf[tw]), acc[mt], 0, 0, 0);
@@ -238,8 +269,19 @@ __global__ __launch_bounds__(64 * K1S_WAVES, (RIDER && !GE) ? 4 : 2) void k1_str
                     // (ADAPTIVE, first pass over the ring: plus the map loads issued behind the first slots)
                     if (2 * (si + K1S_D - 1) + 1 < my_steps) { if (adaptive && s0 == 0) wait_vmcnt<4 * (K1S_D - 1) + NF>(); else wait_vmcnt<4 * (K1S_D - 1)>(); }
                     else wait_vmcnt<0>();
-                    compute(d, 0, 2 * si);
-                    if (2 * si + 1 < my_steps) compute(d, 1, 2 * si + 1);
+                    // (The two waves of a SIMD -- w and w + 4 -- are arbitrated by priority, then AGE: the older wave runs nearly unimpeded,
+                    //  waves 4-7 leave this loop ~2.2 us after waves 0-3.  Alternating s_setprio slot by slot, opposite in the two partners,
+                    //  evened them out (gap 1.0 us) and slowed the older ones by as much: zero-sum, not kept.)
+                    float x0[8], x1[8];
+                    uint32_t b0[2], b1[2];
+                    const char* base = ring + (d * 2 * 2) * 1024 + (8 * kg) * 128 + 4 * n;
+                    const int j0 = K1S_WAVES * (2 * si) + w, j1 = j0 + K1S_WAVES;      // K16 steps inside the slice: bytes 2 j, 2 j + 1 of a batch row
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { x0[j] = *reinterpret_cast<const float*>(base + j * 128); x1[j] = *reinterpret_cast<const float*>(base + 2048 + j * 128); }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) { b0[mt] = abl[(2 * j0 + kg) * 64 + 32 * mt + n]; b1[mt] = abl[(2 * min(j1, nsteps - 1) + kg) * 64 + 32 * mt + n]; }
+                    math(x0, b0, 0);
+                    if (2 * si + 1 < my_steps) math(x1, b1, 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's fragments are in registers: refill it
                     issue_slot(d, si + K1S_D);
                 }
@@ -258,6 +300,7 @@ __global__ __launch_bounds__(64 * K1S_WAVES, (RIDER && !GE) ? 4 : 2) void k1_str
     }
     if (!known_real) wait_vmcnt<0>();                     // (announced real values: the rings requested in the prologue stay in flight)
     stamp(st, sblk, 2);
+    if (st && tid == 64 * (K1S_WAVES - 1) && sblk < 4096) g_stamps[sblk * 8 + 7] = wall_clock64();      // (tuning aid: when the youngest wave leaves the loop)
     __syncthreads();                                      // every wave is done with its ring (the area becomes red[8][64][32]); the mask words are complete
     if constexpr (REAL) {
         if (adaptive) mlo = __builtin_amdgcn_readfirstlane(smask[0] | smask[1] | smask[2] | smask[3]);      // items 0 .. 31 of the slice
@@ -283,7 +326,7 @@ __global__ __launch_bounds__(64 * K1S_WAVES, (RIDER && !GE) ? 4 : 2) void k1_str
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(base + j * 128);
             uint4 bf[NW];
-            make_w_frags<NW>(x, bf);
+            make_w_frags_rne<NW>(x, bf);
             const int jstep = K1S_WAVES * i + w, item = jstep >> 2;
             const bool isbin = a.amode == K1S_ADAPTIVE && ((mlo >> (item & 31)) & 1u) == 0u;      // wave-uniform
 #pragma unroll

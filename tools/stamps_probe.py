@@ -32,6 +32,8 @@ for which, bit, nslots in (("K1 k1_stream POSITIVE phase: start, bits+ring lande
     a = np.frombuffer(buf, dtype=np.int64).reshape(4096, 8).copy()
     nb = int((a[:, 0] > 0).sum())
     if bit in (64, 2048):      # k1_stream: only the last arriver of a tile has slots 5, 6
+        w7 = (a[:nb, 7] - a[:nb, 2]).astype(np.float64) / 100.0
+        print(f"== k1_stream: the youngest wave leaves the K loop after wave 0 by (us): p10 {np.percentile(w7, 10):.2f} p50 {np.percentile(w7, 50):.2f} p90 {np.percentile(w7, 90):.2f} max {w7.max():.2f}")
         last = a[:nb][a[:nb, 6] > 0]
         b = last[:, :7].astype(np.float64) / 100.0
         b -= a[:nb, 0].min() / 100.0

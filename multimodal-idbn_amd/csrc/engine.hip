@@ -1264,17 +1264,16 @@ int imdbn_rbm_prefetch_ok(const imdbn_rbm_desc* d, int B) {
     return prefetch_available(d) ? 1 : 0;
 }
 
-// bias / sparsity / error tail of the packed statistics buffer (after the V*H delta-W floats)
-static int launch_pack(Ctx& c, float* packed) {
+// bias / sparsity / error tail of the packed statistics buffer (after the V*H delta-W floats): written by the extra block row of the
+// statistics kernel (BiasArgs::pack_tail) instead of a launch of its own
+static BiasArgs make_pack(Ctx& c, float* packed) {
     const imdbn_rbm_desc* d = c.d;
-    PackArgs p;
-    memset(&p, 0, sizeof(p));
-    p.tail = packed + (size_t)d->V * d->H; p.H = d->H; p.V = d->V;
-    p.hpos = c.L.cs_hpos; p.hneg = c.L.cs_hneg; p.vpos = c.L.cs_vpos; p.vneg = c.L.cs_vneg; p.P = c.L.P;
-    p.loss_part = c.L.loss_part; p.n_loss = n_loss_used(c, false);
-    hipLaunchKernelGGL(pack_stats, dim3(cdiv(std::max(d->V, d->H), 256) + 1), dim3(256), 0, c.s, p);
-    HIPCHK(hipGetLastError());
-    return 0;
+    BiasArgs b;
+    memset(&b, 0, sizeof(b));
+    b.pack_tail = packed + (size_t)d->V * d->H; b.H = d->H; b.V = d->V;
+    b.hpos = c.L.cs_hpos; b.hneg = c.L.cs_hneg; b.vpos = c.L.cs_vpos; b.vneg = c.L.cs_vneg; b.P = c.L.P;
+    b.loss_part = c.L.loss_part; b.n_loss = n_loss_used(c, false);
+    return b;
 }
 
 size_t imdbn_packed_delta_floats(int V, int H) {
@@ -1288,10 +1287,13 @@ int imdbn_rbm_cd_stats(const imdbn_rbm_desc* d, const float* data, int64_t ldd, 
     if (!data || !o || !packed || ldd < d->V) return fail(IMDBN_E_INVALID, "cd_stats: bad argument");
     Ctx c(d, rng, S(stream));
     CHK(setup(c, B, ws, ws_bytes));
-    CHK(cd_phases(c, data, ldd, o));
+    PrepArgs pn;
+    bool rides = false;
+    CHK(cd_prologue(c, o, pn, rides));          // the next-batch preparation / prefetch slot of imdbn_rbm_cd_step
+    CHK(cd_phases(c, data, ldd, o, rides ? &pn : nullptr));
     CHK(c.rng.finish());
-    CHK(launch_assoc(c, 1, o, c.nw == 1 ? 1 : 0, c.L.flags, 1, 1.0f, packed));
-    CHK(launch_pack(c, packed));
+    const BiasArgs pack = make_pack(c, packed);
+    CHK(launch_assoc(c, 1, o, c.nw == 1 ? 1 : 0, c.L.flags, 1, 1.0f, packed, &pack));
     return 0;
 }
 
@@ -1643,8 +1645,8 @@ int imdbn_rbm_clamped_stats(const imdbn_rbm_desc* d, const float* v_known, const
     CHK(setup(c, B, ws, ws_bytes));
     CHK(clamped_phases(c, v_known, mask, ldk, n_init, init_steps, mu, ldmu, Dz, o));
     CHK(c.rng.finish());
-    CHK(launch_assoc(c, 1, o, c.rt, nullptr, o->sample_v ? 1 : c.rt, 1.0f, packed));
-    CHK(launch_pack(c, packed));
+    const BiasArgs pack = make_pack(c, packed);
+    CHK(launch_assoc(c, 1, o, c.rt, nullptr, o->sample_v ? 1 : c.rt, 1.0f, packed, &pack));
     return 0;
 }
 

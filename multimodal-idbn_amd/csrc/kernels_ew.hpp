@@ -755,6 +755,8 @@ struct BiasArgs {
     int P; float lr, mom, n; int sparsity; float target;
     const float* loss_part; int n_loss; float loss_den; float* loss_out;
     int R; int64_t rs;           // factor-exchange mode: the partials of R ranks, rs floats apart (R <= 1: one set)
+    float* pack_tail;            // statistics mode (data-parallel all-reduce): no update -- the tail of the packed buffer
+                                 // [dc (H) | db (V) | sum P+ (H) | squared error] is written instead (what the pack_stats launch did)
 };
 
 __device__ __forceinline__ float sum_parts(const float* p, int P, int len, int i) {
@@ -788,6 +790,22 @@ __device__ __forceinline__ double loss_total_256(const float* part, int n, doubl
 // Work of `nblk` 256-thread blocks: block `blk` == nblk-1 reduces the squared-error partials, the others
 // stride over the bias vectors.  Used by the stand-alone kernel and by the extra block row of K3.
 __device__ __forceinline__ void bias_work(const BiasArgs& a, int blk, int nblk, double* sh) {
+    if (a.pack_tail) {
+        if (blk == nblk - 1) {
+            const double t = loss_total_256(a.loss_part, a.n_loss, sh);
+            if (threadIdx.x == 0) a.pack_tail[2 * a.H + a.V] = (float)t;
+            return;
+        }
+        for (int i = blk * 256 + threadIdx.x; i < max(a.V, a.H); i += (nblk - 1) * 256) {
+            if (i < a.H) {
+                const float sp = sum_parts(a.hpos, a.P, a.H, i), sn = sum_parts(a.hneg, a.P, a.H, i);
+                a.pack_tail[i] = sp - sn;
+                a.pack_tail[a.H + a.V + i] = sp;
+            }
+            if (i < a.V) a.pack_tail[a.H + i] = sum_parts(a.vpos, a.P, a.V, i) - sum_parts(a.vneg, a.P, a.V, i);
+        }
+        return;
+    }
     if (blk == nblk - 1) {
         if (a.loss_out) {
             double t = 0.0;

@@ -442,8 +442,9 @@ class HipEngine:
             buf = self._ws[key] = torch.zeros(self.packed_floats(W.shape[0], W.shape[1]), device=W.device)
         return buf
 
-    def cd_stats(self, rbm, data, cd_k, rng, out: Optional[torch.Tensor] = None, data_binary=None):
-        d = self._desc(rbm, False)
+    def cd_stats(self, rbm, data, cd_k, rng, out: Optional[torch.Tensor] = None, data_binary=None, next_data=None):
+        """The shard's packed statistics (data-parallel all-reduce exchange); ``next_data``: the next-batch hint of ``cd_step``."""
+        d = self._desc(rbm, True)       # (imdbn_rbm_prefetch_ok wants the full descriptor)
         x = _f32c(data, "data")
         B, dev = x.size(0), x.device
         o = self._opts(rbm, 0.0, 0.0, cd_k)
@@ -453,9 +454,12 @@ class HipEngine:
         n = self.packed_floats(d.V, d.H)
         packed = out if out is not None else torch.zeros(n, device=dev)
         ws = self._workspace(dev, d.V, d.H, B)
+        key, nxt = self._prefetch_opts(o, d, x, next_data)
         N.check(self._lib.imdbn_rbm_cd_stats(C.byref(d), _ptr(x), x.stride(0), B, C.byref(o), C.byref(r), _ptr(packed),
                                               _ptr(ws), ws.numel(), self._stream(dev)), "imdbn_rbm_cd_stats")
         self._done(rng, r, sched)
+        if nxt is not None:
+            self._pf[key] = (self._ident(nxt), int(o.next_slot), nxt)
         return packed
 
     # ---- data-parallel factor exchange (include/imdbn_engine.h) --------------------------------------

@@ -233,7 +233,7 @@ class RBM(nn.Module):
                     gathered = dp.all_gather_blocks(eng.gather_buffer(self, B, dp.world_size()), block)
                 return ret(eng.apply_factors(self, gathered, B, B * dp.world_size(), lr, mom))
             buf = eng.packed_buffer(self) if hasattr(eng, "packed_buffer") else None
-            packed = eng.cd_stats(self, x, CD, rng, out=buf, **kw)
+            packed = eng.cd_stats(self, x, CD, rng, out=buf, **kw, **({"next_data": next_data} if (next_data is not None and hasattr(eng, "prefetch_ok")) else {}))
             dp.all_reduce_sum(packed)
             return ret(eng.apply_delta(self, packed, B * dp.world_size(), lr, mom))
         if return_forward:

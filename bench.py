@@ -58,6 +58,7 @@ os.environ.setdefault("MKL_NUM_THREADS", str(CPU_SHARE))
 
 V, H, B = 10000, 1500, 64
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
 TRAFFIC_JSON = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
 
@@ -153,8 +154,14 @@ def other_configs(dev):
                         else:
                             r.train_epoch(v, 0, 1, CD=1, next_data=nd)
             t = timeit(c2, 4, 1) / len(xb)
+            # algorithmic bytes of one batch through both layers: a CD-1 update streams W three times and
+            # read-modify-writes W and W_m once (7 x 4VH bytes), the forward for the next layer reads W once more
+            c2_bytes = 8 * 4 * 10000 * 1500 + 7 * 4 * 1500 * 500
             out["C2_stack"] = {"ms_per_batch": 1e3 * t, "batches_per_s": 1.0 / t, "bound": "layer 1 HBM (see roofline); layer 2 + forwards launch/latency",
-                               "ref_cpu_ms_per_batch": 213.0}
+                               "ref_cpu_ms_per_batch": 213.0,
+                               "roofline": {"bound": "hbm", "achieved": c2_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": c2_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                            "note": "bytes = 8 x 4VH (layer 1: three reads + W, W_m read-modify-write + the forward) + 7 x 4VH (layer 2)"}}
 
             jr = RBM(532, 256, 0.04, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=[(500, 532)]).to(dev)
             z = torch.rand(64, 500, device=dev)
@@ -174,8 +181,14 @@ def other_configs(dev):
                 for _ in range(2):
                     jr.train_epoch_clamped(vk, km, 0, 20, CD=1, cond_init_steps=30, sample_h=False, sample_v=False,
                                            aux_lr_mult=0.3, use_noisy_init=True)
-            out["C3_joint_532x256"] = {"main_step_ms": 1e3 * timeit(c3_main, 20), "warmup_step_ms": 1e3 * timeit(c3_warm, 20),
-                                       "bound": "dependency latency (61 half steps on a 545 KB matrix)", "ref_cpu_main_ms": 30.7}
+            t3 = timeit(c3_main, 20)
+            out["C3_joint_532x256"] = {"main_step_ms": 1e3 * t3, "warmup_step_ms": 1e3 * timeit(c3_warm, 20),
+                                       "bound": "dependency latency (61 half steps on a 545 KB matrix)", "ref_cpu_main_ms": 30.7,
+                                       # no bandwidth or MFMA roofline binds a 545 KB matrix: the unit is the dependent half step
+                                       "roofline": {"bound": "latency", "achieved": 1e6 * t3 / 66.0, "peak": None, "unit": "us per dependent half step",
+                                                    "frac": None, "traffic": None,
+                                                    "note": "66 dependent half steps per main step (CD-1 update: 3 + its update; clamped update: 2 x 30 init + 3); "
+                                                            "the chain kernel runs them in one launch (DESIGN.md 9.4)"}}
 
             m = iMDBN([10000, 1500, 500], 256, params=dict(params), dataloader=dl, val_loader=dl, device=dev, num_labels=32)
             m.z_class_mean = torch.rand(32, 500, device=dev)
@@ -185,9 +198,38 @@ def other_configs(dev):
             m.live_best_of_k, m.best_of_k = True, 16      # K=16 with live free-energy selection
             t5k = timeit(lambda: m._cross_reconstruct(z5, y5, steps=50), 10)
             td = timeit(lambda: m.image_idbn.decode(z5), 10)
+            xr = (torch.rand(256, 10000, device=dev) > 0.9).float()
+            tr = timeit(lambda: m.image_idbn.represent(xr), 10)
+            # decode / represent of 256 real-valued rows: 9 bf16 products per fp32 product (3 x 3 terms), dense bf16 MFMA peak
+            dec_flops = 2.0 * 256 * (500 * 1500 + 1500 * 10000) * 9
             out["C5_cross_reconstruct_b256_s50"] = {"ms_default_k5_inert": 1e3 * t5, "ms_live_k16": 1e3 * t5k, "decode_ms": 1e3 * td,
-                                                    "decode_frac_hbm": 63.0e6 / td / (HBM_PEAK_GBS * 1e9),
-                                                    "bound": "chains: dependency latency; decode: HBM (63 MB of weights)", "ref_cpu_ms": 263.0}
+                                                    "represent_ms": 1e3 * tr,
+                                                    "bound": "chains: dependency latency; decode / represent: MFMA (9 bf16 products per fp32 product)",
+                                                    "ref_cpu_ms": 263.0,
+                                                    "roofline": {"bound": "latency", "achieved": 1e6 * (t5 - td) / 100.0, "peak": None,
+                                                                 "unit": "us per dependent chain step", "frac": None, "traffic": None,
+                                                                 "note": "2 chains x 50 steps in one launch of the chain kernel, then the decode"},
+                                                    "decode_roofline": {"bound": "mfma", "achieved": dec_flops / td / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                                                        "unit": "TFLOP/s", "frac": dec_flops / td / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                                                        "note": "bf16 MFMA flops issued = 9 x 2 x 256 x (500x1500 + 1500x10000); wall time of "
+                                                                                "iDBN.decode (4 launches)"}}
+
+            # iMDBN.train_joint (imdbn.py:540-640): the C3 updates + the per-batch cross-modal metrics, overlapped on a second stream
+            yj = torch.randint(0, 32, (len(X),))
+            dlj = DataLoader(TensorDataset(X.to(dev), torch.eye(32)[yj].to(dev)), batch_size=64, shuffle=False)
+            import contextlib, io
+            tj = {}
+            for ov in (True, False):
+                mj = iMDBN([10000, 1500, 500], 256, params=dict(params, JOINT_METRICS_OVERLAP=ov), dataloader=dlj, val_loader=dlj, device=dev, num_labels=32)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    mj.train_joint(2)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    mj.train_joint(4)
+                    torch.cuda.synchronize()
+                tj[ov] = (time.perf_counter() - t0) / (4 * len(dlj))
+            out["C3_train_joint_loop"] = {"ms_per_batch": 1e3 * tj[True], "ms_per_batch_metrics_inline": 1e3 * tj[False],
+                                          "bound": "dependency latency; the metrics' chains run on a second stream against a snapshot of the joint RBM"}
         finally:
             os.chdir(cwd)
     return out

@@ -51,6 +51,7 @@ struct Tuning {
     int no_adaptive = 0;             // testing: a prefetched batch of unknown content gets all three-term forms (no per-item choice)
     int k1s_lds_pad = 0;             // experiment: extra dynamic LDS (bytes) for the bit-plane k1_stream
     int no_chain_pair = 0;           // testing: imdbn_rbm_chain_pair runs its chains one after the other
+    int no_down_chunks = 0;          // testing: the fused K2 of a multi-chunk batch runs one block per (tile, 64-row chunk)
     int k1s_force_na = 0;            // experiment: bit-plane operands run on the kernel instantiation that can also read bf16 terms
 };
 Tuning g_defaults;
@@ -78,6 +79,7 @@ inline const Tuning& tune() { return t_bound ? *t_bound : g_defaults; }
 #define g_k1s_lds_pad (tune().k1s_lds_pad)
 #define g_k1s_force_na (tune().k1s_force_na)
 #define g_no_chain_pair (tune().no_chain_pair)
+#define g_no_down_chunks (tune().no_down_chunks)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
@@ -554,18 +556,29 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         // tiles cover [0, Vpad): the K16-blocked operand form must have its padding columns [V, Vpad) written (zeros) -- the
         // next K1 multiplies them with clamped (non-zero) weight rows.  Tiles of 20 / 24 / 28 rows (chosen for V in
         // (4096, 7168]) do not end on a multiple of 16 by themselves; found by tools/stress_parity.py.
-        dim3 grid(cdiv(L.Vpad, L.down_tr), 1, mb);
-        c.down_blocks = (int)grid.x;
-        f.dbg = g_dbg;
-        if (f.op.bits && (L.down_tr % 8 != 0 || f.n_groups > 0 || f.vmode == 0)) f.op.bits = nullptr;      // not a 0/1 plane the epilogue can write byte-wise
-        f.op.bits_shape = 1; f.op.bits_cols = L.down_tr;
         // sampled hidden states left by `finish` in bit-packed form: 16x less activation traffic per block
         const uint8_t* abits = (c.hid_bits_ok && in.rm == L.hid_rm && in.terms == 1 && !g_no_bits) ? L.hid_bits : nullptr;
         const int64_t ats = (int64_t)L.Bp * L.Hpad;
         const bool vec4 = (d->ldw % 4 == 0) && (((uintptr_t)d->W & 15) == 0) && (L.H % 4 == 0) && L.H >= 4;
-        if ((int)((grid.x + IMDBN_MAX_GROUPS) * grid.z) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
+        // several 64-row batch chunks: one block per weight tile takes 2 or 4 of them, a wave (pair) per chunk, on full 32-row
+        // tiles (decode / visible_probs of a 256-row batch: 4 x 500 blocks of 20 rows in four rounds -> 313 blocks in one)
+        const int mbb = (mb >= 2 && !abits && !next && vec4 && !(f.rm_src && f.op.rm) && !g_no_down_chunks && L.Vpad >= 128 * 32)
+                            ? (mb % 4 == 0 ? 4 : (mb % 2 == 0 ? 2 : 1)) : 1;      // (fewer than 128 weight tiles: the per-chunk grid fills the chip better)
+        const int down_tr = mbb > 1 ? 32 : L.down_tr;
+        dim3 grid(cdiv(L.Vpad, down_tr), 1, mb / mbb);
+        c.down_blocks = (int)grid.x;
+        f.dbg = g_dbg;
+        if (f.op.bits && (down_tr % 8 != 0 || f.n_groups > 0 || f.vmode == 0)) f.op.bits = nullptr;      // not a 0/1 plane the epilogue can write byte-wise
+        f.op.bits_shape = 1; f.op.bits_cols = down_tr;
+        if ((int)((grid.x + IMDBN_MAX_GROUPS) * mb) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
+#define LAUNCH_DOWN_M(NW, MBBV) \
+    hipLaunchKernelGGL((gemm_down_fused<NW, true, 0, false, MBBV>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f, down_tr, abits, L.ldbits)
+        if (mbb > 1) {
+            if (c.nw == 3) { if (mbb == 4) LAUNCH_DOWN_M(3, 4); else LAUNCH_DOWN_M(3, 2); }
+            else           { if (mbb == 4) LAUNCH_DOWN_M(1, 4); else LAUNCH_DOWN_M(1, 2); }
+        } else
 #define LAUNCH_DOWN(NW, V4, NAK, BITS) \
-    hipLaunchKernelGGL((gemm_down_fused<NW, V4, NAK, BITS>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f, L.down_tr, abits, L.ldbits)
+    hipLaunchKernelGGL((gemm_down_fused<NW, V4, NAK, BITS>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f, down_tr, abits, L.ldbits)
 #define LAUNCH_DOWN_A(NW, V4) \
     do { if (abits) LAUNCH_DOWN(NW, V4, 1, true); else if (in.terms == 1) LAUNCH_DOWN(NW, V4, 1, false); \
          else if (in.terms == 3) LAUNCH_DOWN(NW, V4, 3, false); else LAUNCH_DOWN(NW, V4, 0, false); } while (0)
@@ -575,7 +588,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
             const int main_nbx = (int)grid.x;
             dim3 gn(grid.x + cdiv(std::max(next->N, next->op.ldrm), 64), 1, mb);
 #define LAUNCH_DOWN_N(NW, BITS) \
-    hipLaunchKernelGGL((gemm_down_fused_next<NW, BITS>), gn, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, f, L.down_tr, abits, L.ldbits, *next, main_nbx)
+    hipLaunchKernelGGL((gemm_down_fused_next<NW, BITS>), gn, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, f, down_tr, abits, L.ldbits, *next, main_nbx)
             if (c.nw == 3) { if (abits) LAUNCH_DOWN_N(3, true); else LAUNCH_DOWN_N(3, false); }
             else           { if (abits) LAUNCH_DOWN_N(1, true); else LAUNCH_DOWN_N(1, false); }
 #undef LAUNCH_DOWN_N
@@ -586,7 +599,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
 #undef LAUNCH_DOWN
         HIPCHK(hipGetLastError());
         if (f.n_groups > 0 && !f.logits_only) {
-            hipLaunchKernelGGL(finish_groups, dim3(f.n_groups, L.Bp / 64), dim3(256), 0, c.s, f, (int)(grid.x * grid.z));
+            hipLaunchKernelGGL(finish_groups, dim3(f.n_groups, L.Bp / 64), dim3(256), 0, c.s, f, (int)(grid.x * mb));
             HIPCHK(hipGetLastError());
         }
         return 0;
@@ -1004,6 +1017,7 @@ static int set_opt(Tuning& t, const char* name, int value) {
     else if (!strcmp(name, "no_adaptive")) t.no_adaptive = value;
     else if (!strcmp(name, "k1s_force_na")) t.k1s_force_na = value;
     else if (!strcmp(name, "no_chain_pair")) t.no_chain_pair = value;
+    else if (!strcmp(name, "no_down_chunks")) t.no_down_chunks = value;
     else if (!strcmp(name, "k1s_lds_pad")) t.k1s_lds_pad = std::max(0, std::min(value, 64 * 1024));
     else if (!strcmp(name, "no_fused_up")) t.no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);

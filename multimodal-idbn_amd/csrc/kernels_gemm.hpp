@@ -333,7 +333,10 @@ __device__ __forceinline__ uint4 bits_to_frag(uint32_t byte) {
     return make_uint4(d[0], d[1], d[2], d[3]);
 }
 
-template <bool UP, int NW, bool VEC4, int NA, bool BITS = false>
+// MBB = 64-row batch chunks per block (1, 2 or 4): the four waves are dealt MBB chunks x (4 / MBB) K shares, so a 256-row
+// batch takes ONE block per weight tile (every wave a chunk of its own over the whole K, no K shares to combine) instead
+// of four blocks in four rounds of the grid.  MBB = 1 is the arrangement described above.
+template <bool UP, int NW, bool VEC4, int NA, bool BITS = false, int MBB = 1>
 __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int64_t ldw, int K, int N,
                                                 const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
                                                 const FinishArgs& fa, float* red /*[4][32][64]*/, float (*tile)[33], int TR,
@@ -345,7 +348,9 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     // the block owns output columns [n0, n0 + TR), TR <= 32 (host: plan_down_rows); MFMA lanes >= TR repeat the last
     // column (same addresses -> no extra traffic) and their results are dropped
     const int r = l & 31, rc = min(r, TR - 1);
-    const int n0 = bx * TR, mb = bz * 64;
+    constexpr int KW = 4 / MBB;              // waves sharing one batch chunk's K range
+    const int kw = w % KW, cb = w / KW;
+    const int n0 = bx * TR, mb = (bz * MBB + cb) * 64;
     f32x16 acc[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -406,26 +411,30 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
     // K blocks are dealt to the waves in groups of D CONSECUTIVE blocks (group g of wave w = blocks
     // (4g+w)*D .. +D-1), so one pass over the ring reads D*64 B = 256 contiguous bytes of every weight row
     // (whole 128-B lines per wave instead of lines split between waves).  Register ring, static slots.
-    DownOperands<NA> ring[D];
     const int nblk = lda / 16;
     const int sblk = bz * nbx + bx;
     const bool st = (fa.dbg & 128) != 0;
     stamp(st, sblk, 1);
+    DownOperands<NA> ring[D];
     // epilogue side inputs (bias, loss reference, clamp / mu planes) of this thread's column x 8 rows: issued now,
     // consumed after the K loop (their first-touch latency used to sit on every block's critical path)
     SideIn<8> side;
-    load_side<8>(fa, (tid & 31) < TR ? n0 + (tid & 31) : (1 << 30), mb + (tid >> 5) * 8, side);
+    if constexpr (MBB == 1) load_side<8>(fa, (tid & 31) < TR ? n0 + (tid & 31) : (1 << 30), bz * 64 + (tid >> 5) * 8, side);
 #pragma unroll
-    for (int d = 0; d < D; ++d) load(ring[d], 16 * (w * D + d));
-    for (int g = 0; (4 * g + w) * D < nblk; ++g) {
+    for (int d = 0; d < D; ++d) load(ring[d], 16 * (kw * D + d));
+    for (int g = 0; (KW * g + kw) * D < nblk; ++g) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             __builtin_amdgcn_sched_barrier(0);
-            if ((4 * g + w) * D + d < nblk) compute(ring[d]);             // wave-uniform
+            if ((KW * g + kw) * D + d < nblk) compute(ring[d]);           // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
-            load(ring[d], 16 * ((4 * (g + 1) + w) * D + d));              // refill the slot for the next group
+            load(ring[d], 16 * ((KW * (g + 1) + kw) * D + d));            // refill the slot for the next group
         }
     }
+    // (Tried for the multi-chunk form, 256 x 1500 -> 10000, 118 us as above: ring slots of TWO K16 blocks loaded together so that
+    //  the four dwordx4 weight loads of a lane pair fall into one 128-byte line back to back: 125 us; the same with lane (r, hh)
+    //  taking 16 consecutive floats and the activations from block 2j + hh: 139 us.  The 32-of-128-byte weight reads per
+    //  instruction are not what bounds this kernel.)
     // cross-wave reduction (fixed order) into tile[batch row][column]
     stamp(st, sblk, 2);
     __syncthreads();
@@ -435,49 +444,63 @@ __device__ __forceinline__ void down_fused_body(const float* __restrict__ W, int
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) red[((w * 2 + mt) * 16 + reg) * 64 + l] = acc[mt][reg];
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = w * 8 + i, mt = c >> 4, reg = c & 15;
-        const float s = ((red[((0 * 2 + mt) * 16 + reg) * 64 + l] + red[((1 * 2 + mt) * 16 + reg) * 64 + l]) +
-                         red[((2 * 2 + mt) * 16 + reg) * 64 + l]) + red[((3 * 2 + mt) * 16 + reg) * 64 + l];
-        tile[mt * 32 + mfma_row(reg, l)][r] = s;
-    }
-    __syncthreads();
-    // epilogue: 256 threads = 32 columns x 8 row-octets
     const int c = tid & 31, oct = tid >> 5;
     const int ecol = c < TR ? n0 + c : (1 << 30);          // columns past the tile: nothing stored
-    float xs[8];
+#pragma unroll 1
+    for (int ch = 0; ch < MBB; ++ch) {                     // the block's batch chunks, one after the other through `tile`
+        const int mbc = (bz * MBB + ch) * 64;
+        if constexpr (MBB > 1) load_side<8>(fa, ecol, mbc + oct * 8, side);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xs[i] = tile[oct * 8 + i][c];
-    float lsum = 0.f;
-    stamp(st, sblk, 4);
-    // the reduction buffer is free again: it stages the K16-blocked operand tile [term][2 column groups][64 rows][16]
-    const bool staged = fa.rm_src && !fa.logits_only && TR == 32;      // needs 16-column-aligned tiles
-    const RmStage stg{reinterpret_cast<bf16_t*>(red), 2, 64, n0, mb};
-    lsum = finish_rows8(fa, ecol, mb + oct * 8, xs, (mb >> 3) + oct, side, staged ? stg : RmStage{});
-    stamp(st, sblk, 5);
-    if (staged) {
+        for (int i = 0; i < 8; ++i) {
+            const int cc = w * 8 + i, mt = cc >> 4, reg = cc & 15;
+            float s;
+            if constexpr (MBB == 1)
+                s = ((red[((0 * 2 + mt) * 16 + reg) * 64 + l] + red[((1 * 2 + mt) * 16 + reg) * 64 + l]) +
+                     red[((2 * 2 + mt) * 16 + reg) * 64 + l]) + red[((3 * 2 + mt) * 16 + reg) * 64 + l];
+            else if constexpr (MBB == 2)
+                s = red[(((2 * ch) * 2 + mt) * 16 + reg) * 64 + l] + red[(((2 * ch + 1) * 2 + mt) * 16 + reg) * 64 + l];
+            else
+                s = red[((ch * 2 + mt) * 16 + reg) * 64 + l];
+            tile[mt * 32 + mfma_row(reg, l)][r] = s;
+        }
         __syncthreads();
-        flush_rm_stage(fa.op, stg);
-    }
-    stamp(st, sblk, 6);
-    if (fa.loss_part) {
-        __syncthreads();
-        const float t = wave_sum(lsum);
-        if (l == 0) red[w] = t;
-        __syncthreads();
-        if (tid == 0) fa.loss_part[bz * nbx + bx] = ((red[0] + red[1]) + red[2]) + red[3];
+        // epilogue: 256 threads = 32 columns x 8 row-octets
+        float xs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xs[i] = tile[oct * 8 + i][c];
+        float lsum = 0.f;
+        stamp(st, sblk, 4);
+        // the reduction buffer is free again: it stages the K16-blocked operand tile [term][2 column groups][64 rows][16]
+        // (single-chunk blocks only: the other chunks' sums are still in it otherwise; the host keeps such launches at MBB = 1)
+        const bool staged = MBB == 1 && fa.rm_src && !fa.logits_only && TR == 32;      // needs 16-column-aligned tiles
+        const RmStage stg{reinterpret_cast<bf16_t*>(red), 2, 64, n0, mbc};
+        lsum = finish_rows8(fa, ecol, mbc + oct * 8, xs, (mbc >> 3) + oct, side, staged ? stg : RmStage{});
+        stamp(st, sblk, 5);
+        if (staged) {
+            __syncthreads();
+            flush_rm_stage(fa.op, stg);
+        }
+        stamp(st, sblk, 6);
+        if (fa.loss_part) {
+            __syncthreads();
+            const float t = wave_sum(lsum);
+            if (l == 0) tile[0][w] = t;                    // (the tile has been read; `red` may still hold the other chunks)
+            __syncthreads();
+            if (tid == 0) fa.loss_part[(bz * MBB + ch) * nbx + bx] = ((tile[0][0] + tile[0][1]) + tile[0][2]) + tile[0][3];
+        }
+        if constexpr (MBB > 1) __syncthreads();            // `tile` is rewritten by the next chunk
     }
 }
 
 // NAK = activation terms known to the host (1 or 3; 0 = decide per block from the exactness map), BITS = the
 // activations are the bit-packed sampled states.  One body per instantiation: several bodies inlined into one kernel
 // make the register allocator spill (scratch) in the hot loop.
-template <int NW, bool VEC4, int NAK, bool BITS>
+template <int NW, bool VEC4, int NAK, bool BITS, int MBB = 1>
 __global__ __launch_bounds__(256, 2) void gemm_down_fused(
     const float* __restrict__ W, int64_t ldw, int K, int N,
     const bf16_t* __restrict__ A, int64_t a_term_stride, int lda, const int* __restrict__ a_flag, int a_terms,
     const FinishArgs fa, int tile_rows, const uint8_t* __restrict__ abits, int ldbits) {
+    static_assert(MBB == 1 || (NAK == 0 && !BITS && VEC4), "several batch chunks per block: real-valued rows, aligned weights");
     __shared__ float red[4 * 32 * 64];
     __shared__ float tile[64][33];
     stamp((fa.dbg & 128) != 0, blockIdx.z * gridDim.x + blockIdx.x, 0);
@@ -489,8 +512,8 @@ __global__ __launch_bounds__(256, 2) void gemm_down_fused(
         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
     } else {
         const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
-        if (na == 1) down_fused_body<false, NW, VEC4, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
-        else         down_fused_body<false, NW, VEC4, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
+        if (na == 1) down_fused_body<false, NW, VEC4, 1, false, MBB>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
+        else         down_fused_body<false, NW, VEC4, 3, false, MBB>(W, ldw, K, N, A, a_term_stride, lda, fa, red, tile, tile_rows, nullptr, 0, blockIdx.x, blockIdx.z, gridDim.x);
     }
 }
 

@@ -261,6 +261,94 @@ def test_config4_eight_ranks_of_64_rows_full_size(_native):
             assert_close(P.N(getattr(rr, k)), getattr(st, k), 1e-4, name + " vs oracle: " + k, atol=2e-6)
 
 
+def test_config4_second_layer_eight_ranks_real_valued_data(_native):
+    """BASELINE configs[3], second layer of the stack: 1500 <-> 500 on REAL-valued data (first-layer probabilities), global batch
+    512 = 8 ranks x 64 rows emulated on one device: factor exchange (fp32 wire form), all-reduce of the packed statistics, the
+    single-process 8-chunk update of the same rows and the oracle must all agree."""
+    from imdbn import engine as E
+    from imdbn.models import RBM
+    V, H, R, Bl = 1500, 500, 8, 64
+    B = R * Bl
+    g = np.random.Generator(np.random.PCG64(43))
+    W0 = (g.standard_normal((V, H), dtype=F32) * F32(0.03)).astype(F32)
+    X = g.random((B, V), dtype=F32)
+
+    def fresh():
+        r = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(DEV)      # constructor layout (padded rows)
+        _poison_and_fill(r, W0)
+        return r
+    eng = _native
+    r1, r2, r3 = fresh(), fresh(), fresh()
+    lr, mom = r1._lr_mom(0)
+    xs = [P.T(X[rk * Bl:(rk + 1) * Bl], DEV) for rk in range(R)]
+    with E.use_rng(E.PhiloxRng(seed=77)):
+        l1 = r1.train_epoch(P.T(X, DEV), 0, 1, CD=1)                          # one rank, eight 64-row chunks
+    dec1 = gpu_cd_samples(eng, DEV, V, H, B)
+    assert eng.factor_mode_ok(r2, Bl)
+    wires = eng.compact_gather_buffer(r2, Bl, R, False)
+    dec2 = []
+    for rk in range(R):                                                         # the production calls of RBM.train_epoch under dp
+        wire = eng.cd_factors_wire(r2, xs[rk], 1, E.PhiloxRng(seed=77, row0=rk * Bl), False)
+        dec2.append(gpu_cd_samples(eng, DEV, V, H, Bl))
+        wires[rk].copy_(wire)
+    dec2 = (np.concatenate([d[0] for d in dec2]), np.concatenate([d[1] for d in dec2]))
+    l2 = eng.apply_wire(r2, wires, Bl, B, False, lr, mom)
+    packed = None
+    for rk in range(R):
+        s = eng.cd_stats(r3, xs[rk], 1, E.PhiloxRng(seed=77, row0=rk * Bl)).clone()
+        packed = s if packed is None else packed + s
+    l3 = eng.apply_delta(r3, packed, B, lr, mom)
+    for r in (r1, r2, r3):
+        _padding_untouched(r)
+    # both exchanges run the same per-rank kernels: identical samples, identical update
+    assert_close(float(l3), float(l2), 1e-6, "loss: all-reduce vs factor exchange")
+    for k in P.KEYS:
+        assert_close(P.N(getattr(r3, k)), P.N(getattr(r2, k)), 1e-5, "all-reduce vs factors: " + k, atol=2e-6)
+    # 0.5 million Bernoulli comparisons: the 8-chunk launch and the 64-row launches split K differently, so a handful of
+    # near-tie samples (|p - u| < 2e-6) may differ between them; each is checked against the oracle with ITS samples at the ties
+    same = all(np.array_equal(a, b) for a, b in zip(dec1, dec2))
+    if same:
+        for k in P.KEYS:
+            assert_close(P.N(getattr(r2, k)), P.N(getattr(r1, k)), 1e-5, "factors vs single process: " + k, atol=2e-6)
+    for name, rr, ll, dec in (("single process", r1, l1, dec1), ("8 ranks", r2, l2, dec2)):
+        st = O.RBMState.create(W0, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95)
+        O.set_tie_break([dec[0], dec[1], None], tol=2e-6)
+        o = O.train_epoch(st, X, 0, 1, PhiloxStream(77))
+        assert O.TIE_BREAK["ties"] < 300 and O.TIE_BREAK["used"] <= 30, dict(O.TIE_BREAK, queue=None)
+        O.set_tie_break(None)
+        assert_close(float(ll), o, 1e-5, name + ": loss vs oracle")
+        for k in P.KEYS:
+            assert_close(P.N(getattr(rr, k)), getattr(st, k), 1e-4, name + " vs oracle: " + k, atol=2e-6)
+
+
+@pytest.mark.parametrize("V,H,B", [(1041, 132, 128), (4200, 160, 128), (4100, 96, 256), (4100, 200, 256), (4321, 1500, 200),
+                                   (10000, 1500, 256), (640, 96, 192)])
+def test_decode_of_a_multi_chunk_batch_one_block_per_weight_tile(_native, V, H, B):
+    """visible_probs / backward (rbm.py:148-151) of more than 64 real-valued rows: one block per 32-row weight tile takes 2 or 4
+    batch chunks (a wave or a wave pair per chunk) instead of one block per (tile, chunk).  Same products, K dealt differently
+    to the waves: equal to the per-chunk launch within fp32 summation order, and to the fp64 value of sigmoid(h W^T + b)."""
+    from imdbn.models import RBM
+    g = np.random.Generator(np.random.PCG64(V + B))
+    W0 = (g.standard_normal((V, H), dtype=F32) / F32(np.sqrt(H))).astype(F32)
+    vb = (g.standard_normal(V, dtype=F32) * F32(0.3)).astype(F32)
+    h = g.random((B, H), dtype=F32)
+    r = RBM(V, H, 0.1, 1e-4, 0.5).to(DEV)
+    _poison_and_fill(r, W0)
+    r.vis_bias.data.copy_(torch.from_numpy(vb))
+    ht = P.T(h, DEV)
+    a = r.backward(ht)
+    _native.set_option("no_down_chunks", 1)
+    try:
+        b = r.backward(ht)
+    finally:
+        _native.set_option("no_down_chunks", 0)
+    ref = 1.0 / (1.0 + np.exp(-(h.astype(np.float64) @ W0.astype(np.float64).T + vb.astype(np.float64))))
+    assert a.shape == (B, V) and torch.isfinite(a).all()
+    assert_close(P.N(a), P.N(b), 2e-6, "chunks in one block vs one block per chunk", atol=1e-7)
+    assert_close(P.N(a), ref.astype(F32), 1e-5, "vs fp64", atol=1e-6)
+    _padding_untouched(r)
+
+
 @pytest.mark.parametrize("live_k", [None, 16])
 def test_config5_cross_reconstruct_full_size_against_oracle(live_k):
     """BASELINE configs[4]: TXT->IMG reconstruction, batch 256, 50-step Gibbs + noisy mean-field anneal with z_class_mean,

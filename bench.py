@@ -58,9 +58,8 @@ os.environ.setdefault("MKL_NUM_THREADS", str(CPU_SHARE))
 
 V, H, B = 10000, 1500, 64
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
-TRAFFIC_JSON = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r03_pmc_hbm_traffic.json")
 
 
 def _cpu_model() -> str:
@@ -141,23 +140,21 @@ def other_configs(dev):
         try:
             X = (torch.rand(64 * 8, 10000) > 0.9).float()
             dl = DataLoader(TensorDataset(X, torch.zeros(len(X), 1)), batch_size=64)
-            d = iDBN([10000, 1500, 500], dict(params), dl, dl, dev)
-            xb = [b[0].to(dev) for b in dl]
-
-            def c2():      # the interleaved layer loop of iDBN.train (idbn.py:195-204) with its next-batch lookahead
-                last = len(d.layers) - 1
-                for i, v in enumerate(xb):
-                    for li, r in enumerate(d.layers):
-                        nd = xb[(i + 1) % len(xb)] if li == 0 else None
-                        if li < last:
-                            _, v = r.train_epoch(v, 0, 1, CD=1, next_data=nd, return_forward=True)
-                        else:
-                            r.train_epoch(v, 0, 1, CD=1, next_data=nd)
-            t = timeit(c2, 4, 1) / len(xb)
+            # C2: the product loop itself (iDBN.train, idbn.py:195-204) over a device-resident sequential loader of 32 batches
+            X2 = (torch.rand(64 * 32, 10000, device=dev) > 0.9).float()
+            dl2 = DataLoader(TensorDataset(X2, torch.zeros(len(X2), 1, device=dev)), batch_size=64, shuffle=False)
+            d = iDBN([10000, 1500, 500], dict(params), dl2, dl2, dev)
+            d.train(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d.train(3)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / (3 * len(dl2))
             # algorithmic bytes of one batch through both layers: a CD-1 update streams W three times and
             # read-modify-writes W and W_m once (7 x 4VH bytes), the forward for the next layer reads W once more
             c2_bytes = 8 * 4 * 10000 * 1500 + 7 * 4 * 1500 * 500
-            out["C2_stack"] = {"ms_per_batch": 1e3 * t, "batches_per_s": 1.0 / t, "bound": "layer 1 HBM (see roofline); layer 2 + forwards launch/latency",
+            out["C2_stack"] = {"ms_per_batch": 1e3 * t, "batches_per_s": 1.0 / t,
+                               "bound": "layer 1 HBM (see roofline); layer 2 + forwards launch/latency",
                                "ref_cpu_ms_per_batch": 213.0,
                                "roofline": {"bound": "hbm", "achieved": c2_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": c2_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -209,8 +206,8 @@ def other_configs(dev):
                                                     "roofline": {"bound": "latency", "achieved": 1e6 * (t5 - td) / 100.0, "peak": None,
                                                                  "unit": "us per dependent chain step", "frac": None, "traffic": None,
                                                                  "note": "2 chains x 50 steps in one launch of the chain kernel, then the decode"},
-                                                    "decode_roofline": {"bound": "mfma", "achieved": dec_flops / td / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                                                        "unit": "TFLOP/s", "frac": dec_flops / td / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                                    "decode_roofline": {"bound": "mfma", "achieved": dec_flops / td / 1e12, "peak": BF16_PEAK_TFLOPS,
+                                                                        "unit": "TFLOP/s", "frac": dec_flops / td / 1e12 / BF16_PEAK_TFLOPS, "traffic": None,
                                                                         "note": "bf16 MFMA flops issued = 9 x 2 x 256 x (500x1500 + 1500x10000); wall time of "
                                                                                 "iDBN.decode (4 launches)"}}
 

@@ -962,7 +962,8 @@ __device__ __forceinline__ void k3_body(const AssocPlanesArgs& a, char* smem, in
                         if constexpr (PASS == 0 || PASS == 3)
                             *reinterpret_cast<float4*>(a.W + idx) = make_float4(w0.x + m.x, w0.y + m.y, w0.z + m.z, w0.w + m.w);   // :213
                         // (non-temporal stores were tried here in round 2: 51.3 us against 49.4 event-timed -- the tail of this kernel is
-                        //  not dirty lines lingering in L2)
+                        //  not dirty lines lingering in L2.  Round 3: write-through (sc1) stores for the LAST tile of every block, so that
+                        //  the launch ends with nothing dirty in the L2s: 46.7 us with and without, rocprofv3, same box)
                     } else {
                         float4 o = d;
                         if constexpr (PASS >= 2) { const float4 p = mc[reg]; o = make_float4(p.x + d.x, p.y + d.y, p.z + d.z, p.w + d.w); }

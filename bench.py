@@ -60,6 +60,7 @@ V, H, B = 10000, 1500, 64
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
 TRAFFIC_JSON = os.path.join("profiles", "r03_pmc_hbm_traffic.json")
+ROCPROF_STATS_CSV = os.path.join("profiles", "r03_bench_kernel_stats.csv")
 
 
 def _cpu_model() -> str:
@@ -462,6 +463,19 @@ def main():
                                "traffic_measured_on_other_sources": stale,
                                "avg_launch_us": 1e6 * avg_s, "launches": k3_n,
                                "algorithmic_bytes_per_launch": 16 * V * H}
+            # the committed rocprofv3 --kernel-trace --stats summary of this command, beside the live event brackets (a bracket
+            # = the launch between two hipEventRecords: it includes the dispatch gap on either side of the kernel, ~3 us)
+            if not use_dp:
+                try:
+                    import csv
+                    for r in csv.DictReader(open(os.path.join(ROOT, ROCPROF_STATS_CSV))):
+                        if "assoc_update_planes" in r["Name"]:
+                            us = float(r["AverageNs"]) / 1e3
+                            out["roofline"].update({"rocprofv3_avg_launch_us": us, "rocprofv3_frac": 16 * V * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                    "rocprofv3_source": ROCPROF_STATS_CSV + (" (other kernel sources)" if stale else "")})
+                            break
+                except Exception:
+                    pass
         else:
             out["roofline"] = None
         out["other_configs"] = other_configs(dev) if (world == 1 and not use_dp and not args.no_other_configs) else None

@@ -384,7 +384,10 @@ int k3_tiles_per_block(int V, int H) {
 // for a span of the update kernel (<= 256 entries); layers outside that read data of unknown content from the bf16 terms throughout
 // (same numbers, all three-term forms prepared).
 bool adaptive_shape_ok(const Layout& L) {
-    return L.k1s_kchunk <= 2048 && 2 * k3_tiles_per_block(L.V, L.H) * L.P <= 256;
+    // ... and one block of the (first batch chunk of the) positive-phase K1 per span of the update kernel for the fix-up of mixed
+    // spans: a narrow hidden layer has too few (found by tools/stress_parity.py: 1576 x 12, 1437 x 32, 2116 x 28)
+    const int tpb = k3_tiles_per_block(L.V, L.H);
+    return L.k1s_kchunk <= 2048 && 2 * tpb * L.P <= 256 && cdiv(cdiv(L.V, 128), tpb) <= L.k1s_tiles * L.k1s_ks;
 }
 
 bool vec4_weights(const imdbn_rbm_desc* d) {

@@ -108,6 +108,25 @@ def test_fresh_untagged_tensors_equal_the_tagged_run_bit_for_bit(kind, n):
     _same(ra, rc, "untagged vs tagged")
 
 
+@pytest.mark.parametrize("V,H,B", [(1576, 12, 201), (1437, 32, 170), (2116, 28, 172), (1100, 4, 64), (3000, 36, 33)])
+@pytest.mark.parametrize("kind", ["binary", "mixed"])
+def test_narrow_hidden_layers_untagged_equal_tagged(V, H, B, kind):
+    """Hidden layers of one or two 32-column tiles: the positive-phase K1 has fewer blocks than the update kernel has spans, so the
+    per-item forms are not used there (tools/stress_parity.py found the internal error the host used to return): fresh untagged
+    tensors with the prefetch == without it == tagged, bit for bit."""
+    xs = _batches(kind, 4, B, V, seed=V)
+    ra, _ = _rbm(V, H, 3)
+    rb, _ = _rbm(V, H, 3)
+    rc, _ = _rbm(V, H, 3)
+    la = _run(ra, xs, None, prefetch=True)
+    lb = _run(rb, xs, None, prefetch=False)
+    lc = _run(rc, xs, kind == "binary", prefetch=True)
+    assert torch.isfinite(la).all()
+    assert torch.equal(la, lb) and torch.equal(la, lc)
+    _same(ra, rb, "prefetched vs prepared in the call")
+    _same(ra, rc, "untagged vs tagged")
+
+
 @pytest.mark.parametrize("kind", ["binary", "real", "mixed"])
 def test_untagged_batches_match_the_oracle(kind):
     """The same three kinds of batches against the numpy oracle (Philox twin) at the north_star tolerance; the seed is the

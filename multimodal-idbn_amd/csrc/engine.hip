@@ -319,6 +319,10 @@ struct Ctx {
     bool data_prepped = false;     // cd_phases: the data-side operands are already in place (prefetch slot)
     int down_blocks = 0;           // blocks (per batch chunk) of the last K2 launch: the number of squared-error partials it left
     bool pos_phase = false;        // tuning aid: the propagation being launched is the positive phase of a CD pass (dbg bit 2048 stamps it, bit 64 the others)
+    bool cnt_ok = false;           // the arrival counters of k1_stream are known to be zero: a launch of THIS call cleared them (prep / chain_init), or the
+                                   // data-side operands come from a prefetch slot (an earlier call on this workspace ran, and every launch leaves them
+                                   // zero).  Otherwise prop() clears them itself: a caller's workspace may hold anything
+                                   // (tools/stress_chains.py on a NaN-filled workspace: chains of a layer wider than 1024 were all NaN)
     bool fix_slot = false;         // the data-side operands were written item by item (PrepArgs::adaptive): the next k1_stream that reads them
                                    // completes the planes of mixed spans for the update kernel (K1sArgs::fix_tr)
     Ctx(const imdbn_rbm_desc* d_, imdbn_rng* r, hipStream_t s_) : d(d_), s(s_), rng(r) {
@@ -452,6 +456,10 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
     const bool k1s_bits = in.bits && (in.binary == 1 || in.binary == 2);
     const bool k1s_real = !k1s_bits && in.rm && !g_no_k1s_real && (in.binary == 0 || (in.binary == 3 && in.bits && in.flag));
     if (up && (k1s_bits || k1s_real) && vec4_weights(d) && !g_no_k1s && !f.logits_only) {
+        if (!c.cnt_ok) {
+            HIPCHK(hipMemsetAsync(L.k1s_cnt, 0, (size_t)mb * L.k1s_tiles * sizeof(int), c.s));
+            c.cnt_ok = true;
+        }
         K1sArgs a;
         memset(&a, 0, sizeof(a));
         a.W = d->W; a.ldw = d->ldw; a.K = L.V; a.N = L.H;
@@ -638,6 +646,7 @@ int prep(Ctx& c, const float* in, int64_t ld, int N, bf16_t* rm, int ldrm, bf16_
     memset(&p, 0, sizeof(p));
     p.op.bits = bits; p.op.bits_shape = 0;
     p.zero = c.L.k1s_cnt; p.n_zero = (c.L.Bp / 64) * c.L.k1s_tiles;      // first launch of a call: arrival counters of k1_stream
+    c.cnt_ok = true;
     p.in = in; p.ld = ld; p.B = c.L.B; p.Bp = c.L.Bp; p.N = N;
     p.op.rm = rm; p.op.ldrm = ldrm; p.op.rm_ts = (int64_t)c.L.Bp * ldrm; p.op.rm_terms = rm ? terms : 0; p.op.Bp = c.L.Bp;
     p.op.tr = tr; p.op.tr_ts = (int64_t)N * c.L.Bp; p.op.tr_terms = terms;
@@ -834,6 +843,8 @@ int chain_init(Ctx& c, const ChainSpec& s, bool forms, bool stats_now) {
         p.op.tr = L.vis_tr[0]; p.op.tr_ts = (int64_t)L.V * L.Bp; p.op.tr_terms = c.rt;
         p.colsum_part = L.cs_vpos;
     }
+    p.zero = L.k1s_cnt; p.n_zero = (L.Bp / 64) * L.k1s_tiles;      // (as prep(): the per-launch chain of a wide layer runs k1_stream)
+    c.cnt_ok = true;
     hipLaunchKernelGGL(prep_operand, dim3(cdiv(L.Vpad, 64), L.P), dim3(256), 0, c.s, p);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1246,7 +1257,7 @@ static int cd_prologue(Ctx& c, const imdbn_cd_opts* o, PrepArgs& pn, bool& rides
         hipLaunchKernelGGL(prep_operand, dim3(cdiv(std::max(pn.N, pn.op.ldrm), 64), c.L.P), dim3(256), 0, c.s, pn);
         HIPCHK(hipGetLastError());
     }
-    if (o->data_slot) { use_slot(c.L, o->data_slot); c.data_prepped = true; c.fix_slot = o->data_binary == IMDBN_DATA_UNKNOWN; }
+    if (o->data_slot) { use_slot(c.L, o->data_slot); c.data_prepped = true; c.cnt_ok = true; c.fix_slot = o->data_binary == IMDBN_DATA_UNKNOWN; }
     return 0;
 }
 

@@ -289,3 +289,30 @@ def test_train_joint_metrics_on_a_second_stream_equal_the_inline_pass(tmp_path):
         for k in ("n", "text_top1", "text_top3", "text_ce", "image_mse", "cd_loss"):
             assert ha[k] == hb[k], (k, ha[k], hb[k])
     assert np.isfinite([h["text_ce"] for h in a.joint_history]).all() and a.joint_history[-1]["n"] == B * NB
+
+
+@pytest.mark.parametrize("V,H,B,wd", [(1089, 480, 64, 14), (1600, 480, 232, 0), (1198, 604, 27, 17)])
+def test_chains_of_a_wide_layer_do_not_depend_on_what_the_workspace_held(V, H, B, wd, _native):
+    """Chains of a layer wider than 1024 run one launch per half step, the h|v ones through k1_stream (real-valued operand).  Its
+    split-K arrival counters live in the caller's workspace, which may hold anything (torch.empty): filled with NaN or with zeros
+    before the call, the chain must give the same finite numbers (tools/stress_chains.py found all-NaN outputs)."""
+    from imdbn import engine as E
+    from imdbn.models import RBM
+    g = np.random.Generator(np.random.PCG64(V + B))
+    Dz = V - wd
+    W0 = (g.standard_normal((V, H), dtype=F32) / F32(np.sqrt(V)) * F32(2.0)).astype(F32)
+    r = RBM(V, H, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=[(Dz, V)] if wd else None)
+    P.set_params(r, DEV, W0, (g.standard_normal(H, dtype=F32) * F32(0.2)).astype(F32), (g.standard_normal(V, dtype=F32) * F32(0.2)).astype(F32))
+    vk = np.zeros((B, V), F32); km = np.zeros((B, V), F32)
+    vk[:, :Dz] = g.random((B, Dz), dtype=F32); km[:, :Dz] = 1
+    outs = []
+    for fill in (float("nan"), 0.0, 1.0e30):
+        _native._workspace(torch.device(DEV), V, H, B).view(torch.float32).fill_(fill)
+        with E.use_rng(E.PhiloxRng(seed=3)):
+            a = r.noisy_meanfield_annealed(P.T(vk, DEV), P.T(km, DEV), n_steps=3)
+            b = r.conditional_gibbs(P.T(vk, DEV), P.T(km, DEV), n_steps=2, sample_h=True)
+        outs.append((a, b))
+    for a, b in outs:
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    for a, b in outs[1:]:
+        assert torch.equal(a, outs[0][0]) and torch.equal(b, outs[0][1])

@@ -100,6 +100,34 @@ for case in range(n_cases):
             fails += 1; print("FAIL", tag, f"margin {margin:.1e}", {k: f"{v:.2e}" for k, v in bad.items()}, flush=True)
     except Exception as e:
         fails += 1; print("ERROR", tag, type(e).__name__, str(e)[:300], flush=True)
+    # the two chains of _cross_reconstruct in one launch (imdbn_rbm_chain_pair) == the two calls, bit for bit (any shape: shapes the
+    # chain kernel does not take run the calls one after the other inside the library)
+    try:
+        if wd:
+            r = RBM(V, H, 0.1, 1e-4, 0.5, **kw); P.set_params(r, DEV, W0, hb, vb)
+            vz = np.zeros((B, V), F32); kz = np.zeros((B, V), F32)
+            vz[:, :Dz] = g.random((B, Dz), dtype=F32); kz[:, :Dz] = 1
+            vy = np.zeros((B, V), F32); ky = np.zeros((B, V), F32)
+            vy[np.arange(B), Dz + g.integers(0, wd, B)] = 1; ky[:, Dz:] = 1
+            gib = dict(v_known=P.T(vz, DEV), known_mask=P.T(kz, DEV), n_steps=n, sample_h=sh, sample_v=sv)
+            nmf = dict(v_known=P.T(vy, DEV), known_mask=P.T(ky, DEV), n_steps=int(g.integers(1, 13)), T0=3.0, T1=1.0, sigma0=0.9, hot_frac=0.7,
+                       sharpen_last=3, T_cold_plus=0.9)
+            pull = {"mu_k": P.T(g.random((B, Dz), dtype=F32), DEV), "eta0": 0.15} if g.random() < 0.7 else None
+            seed = int(g.integers(1, 1 << 30))
+            with E.use_rng(E.PhiloxRng(seed=seed)) as rng:
+                r._mu_pull = pull
+                a1, b1 = r._chain_pair(gib, nmf)
+                used = rng.offset
+            with E.use_rng(E.PhiloxRng(seed=seed)) as rng:
+                r._mu_pull = None
+                a2 = r.conditional_gibbs(**gib)
+                r._mu_pull = pull
+                b2 = r.noisy_meanfield_annealed(**nmf)
+                used2 = rng.offset
+            if not (used == used2 and torch.equal(a1, a2) and torch.equal(b1, b2) and bool(torch.isfinite(a1).all()) and bool(torch.isfinite(b1).all())):
+                fails += 1; print("FAIL (chain pair vs two calls)", tag, f"draws {used} vs {used2}; gibbs differs {int((a1 != a2).sum())}, mean-field differs {int((b1 != b2).sum())}", flush=True)
+    except Exception as e:
+        fails += 1; print("ERROR (chain pair)", tag, type(e).__name__, str(e)[:300], flush=True)
     if case % 25 == 24:
         print(f"... {case + 1} cases, {fails} failures, {ties} near-ties, {time.time() - t0:.0f} s", flush=True)
 print(f"stress_chains: {n_cases} cases, {fails} failures, {ties} near-tie sample flips, {time.time() - t0:.0f} s")

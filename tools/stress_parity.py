@@ -74,6 +74,13 @@ for case in range(n_cases):
             vk[:, :Dz] = Xs[0][:, :Dz]; km[:, :Dz] = 1
             out = P.N(r.conditional_gibbs(P.T(vk, DEV), P.T(km, DEV), n_steps=3))
             lc = float(r.train_epoch_clamped(P.T(vk, DEV), P.T(km, DEV), 2, 10, CD=1, cond_init_steps=10, sample_h=False))
+            # stand-alone propagations on the final weights: forward of the untagged / tagged batch == the fused forward, bit for bit;
+            # backward (visible_probs) of a multi-chunk batch of real-valued rows against the oracle
+            fa = r.forward(P.T(Xs[1], DEV))
+            xt = P.T(Xs[1], DEV); xt._imdbn_binary = bool(binary)
+            fb = r.forward(xt)
+            hq = g.random((B, H), dtype=F32)
+            bw = P.N(r.backward(P.T(hq, DEV)))
         O.reset_margin()
         s = PhiloxStream(seed)
         o0 = O.train_epoch(st, Xs[0], 2, cd, s)
@@ -83,6 +90,9 @@ for case in range(n_cases):
         oc = O.train_epoch_clamped(st, vk, km, 2, s, CD=1, cond_init_steps=10, sample_h=False)
         errs = {"loss0": abs(l0 - o0) / max(abs(o0), 1e-6), "loss1": abs(l1 - o1) / max(abs(o1), 1e-6),
                 "chain": rel(out, oo, 1e-6), "forward": rel(fw, of, 1e-6), "lossc": abs(lc - oc) / max(abs(oc), 1e-4)}
+        errs["backward"] = rel(bw, O.backward(st, hq), 1e-6)
+        errs["forward (final weights)"] = rel(P.N(fa), O.forward(st, Xs[1]), 1e-6)
+        errs["forward untagged vs tagged"] = 0.0 if torch.equal(fa, fb) else 1.0
         for k in P.KEYS:
             errs[k] = rel(P.N(getattr(r, k)), getattr(st, k), 2e-6)
         if FAST:

@@ -46,6 +46,7 @@ for case in range(n_cases):
     if g.random() < 0.4 and V > 40:
         wd = int(g.integers(2, 40)); groups = [(V - wd, V)]
     cd = int(g.integers(1, 3)); binary = g.random() < 0.5
+    mixed = (not binary) and g.random() < 0.5          # 0/1 pixels with a stretch of grey levels and a few exact halves: the per-item forms
     W0 = (g.standard_normal((V, H)) / np.sqrt(V)).astype(F32)
     hb = (g.standard_normal(H) * 0.1).astype(F32); vb = (g.standard_normal(V) * 0.1).astype(F32)
     kw = dict(dynamic_lr=True, final_momentum=0.95, softmax_groups=groups, sparsity=bool(g.random() < 0.3), sparsity_factor=0.1)
@@ -56,8 +57,13 @@ for case in range(n_cases):
     for _ in range(2):
         X = g.random((B, V), dtype=F32)
         X = (X > 0.6).astype(F32) if binary else X
+        if mixed:
+            X = (X > 0.6).astype(F32)
+            wdt = int(g.integers(1, max(2, V // 3))); a0 = int(g.integers(0, V - wdt + 1))
+            X[:, a0:a0 + wdt] = g.random((B, wdt), dtype=F32)
+            X[int(g.integers(0, B)), int(g.integers(0, V)):][:70] = 0.5
         Xs.append(X)
-    tag = f"case {case}: V={V} H={H} B={B} groups={groups} cd={cd} binary={binary} sparsity={kw['sparsity']}"
+    tag = f"case {case}: V={V} H={H} B={B} groups={groups} cd={cd} binary={binary} mixed={mixed} sparsity={kw['sparsity']}"
     def run_once(seed):
         r = RBM(V, H, 0.1, 1e-4, 0.5, **kw)
         P.set_params(r, DEV, W0, hb, vb)

@@ -51,6 +51,7 @@ struct Tuning {
     int no_adaptive = 0;             // testing: a prefetched batch of unknown content gets all three-term forms (no per-item choice)
     int k1s_lds_pad = 0;             // experiment: extra dynamic LDS (bytes) for the bit-plane k1_stream
     int no_chain_pair = 0;           // testing: imdbn_rbm_chain_pair runs its chains one after the other
+    int no_down_tiled = 0;           // testing: multi-chunk real-valued K2 without the LDS-tiled kernel
     int no_down_chunks = 0;          // testing: the fused K2 of a multi-chunk batch runs one block per (tile, 64-row chunk)
     int k1s_force_na = 0;            // experiment: bit-plane operands run on the kernel instantiation that can also read bf16 terms
 };
@@ -80,6 +81,7 @@ inline const Tuning& tune() { return t_bound ? *t_bound : g_defaults; }
 #define g_k1s_force_na (tune().k1s_force_na)
 #define g_no_chain_pair (tune().no_chain_pair)
 #define g_no_down_chunks (tune().no_down_chunks)
+#define g_no_down_tiled (tune().no_down_tiled)
 int g_dbg = 0;    // tuning aid: kernels that record per-block timeline stamps (64 K1, 128 K2, 256 finish, 512 K3; tools/stamps_probe.py)
 
 int fail(int code, const char* fmt, ...) {
@@ -581,6 +583,21 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         f.dbg = g_dbg;
         if (f.op.bits && (down_tr % 8 != 0 || f.n_groups > 0 || f.vmode == 0)) f.op.bits = nullptr;      // not a 0/1 plane the epilogue can write byte-wise
         f.op.bits_shape = 1; f.op.bits_cols = down_tr;
+        // ... and, where the squared-error partials of 32-row tiles fit, the LDS-tiled kernel: 128 weight rows x 64 batch rows per block,
+        // the activation terms staged once per block (kernels_gemm.hpp gemm_down_tiled)
+        if (mbb > 1 && !g_no_down_tiled && (4 * cdiv(L.Vpad, 128) + IMDBN_MAX_GROUPS) * mb <= L.n_loss_slots) {
+            dim3 gt(cdiv(L.Vpad, 128), 1, mb);
+            c.down_blocks = 4 * (int)gt.x;
+            f.op.bits_cols = 32;
+            if (c.nw == 3) hipLaunchKernelGGL((gemm_down_tiled<3>), gt, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f);
+            else           hipLaunchKernelGGL((gemm_down_tiled<1>), gt, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f);
+            HIPCHK(hipGetLastError());
+            if (f.n_groups > 0 && !f.logits_only) {
+                hipLaunchKernelGGL(finish_groups, dim3(f.n_groups, L.Bp / 64), dim3(256), 0, c.s, f, (int)(c.down_blocks * mb));
+                HIPCHK(hipGetLastError());
+            }
+            return 0;
+        }
         if ((int)((grid.x + IMDBN_MAX_GROUPS) * mb) > L.n_loss_slots) return fail(IMDBN_E_INVALID, "internal: loss slots");
 #define LAUNCH_DOWN_M(NW, MBBV) \
     hipLaunchKernelGGL((gemm_down_fused<NW, true, 0, false, MBBV>), grid, dim3(256), 0, c.s, d->W, d->ldw, L.H, L.V, in.rm, ats, L.Hpad, in.flag, in.terms, f, down_tr, abits, L.ldbits)
@@ -1032,6 +1049,7 @@ static int set_opt(Tuning& t, const char* name, int value) {
     else if (!strcmp(name, "k1s_force_na")) t.k1s_force_na = value;
     else if (!strcmp(name, "no_chain_pair")) t.no_chain_pair = value;
     else if (!strcmp(name, "no_down_chunks")) t.no_down_chunks = value;
+    else if (!strcmp(name, "no_down_tiled")) t.no_down_tiled = value;
     else if (!strcmp(name, "k1s_lds_pad")) t.k1s_lds_pad = std::max(0, std::min(value, 64 * 1024));
     else if (!strcmp(name, "no_fused_up")) t.no_fused_up = value != 0;
     else return fail(IMDBN_E_INVALID, "unknown option %s", name);

@@ -1303,4 +1303,141 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
     k3_body<MODE, HT, PASS>(a, smem, bx, by, tiles_per_block, nap, nan_);
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused K2 for MANY real-valued batch rows (decode / visible_probs of >= 128 rows; rbm.py:94-116,148-151, idbn.py:356-359).
+// gemm_down_fused gives every 32-row weight tile its own block, and every block re-reads the activation terms of its batch rows
+// from L2 (2.3 MB per tile at 256 x 1500 x 3 terms: 0.94 GB per launch).  Here a block owns 128 weight rows x 64 batch rows: wave w
+// multiplies rows 32 w .. 32 w + 31 over the WHOLE K, its weight fragments come straight from global memory into registers (each
+// weight is read by exactly one wave), and the activation terms of a K32 slab (NA x 4 KB) are staged ONCE per block by LDS-DMA (two
+// slots) and read by all four waves (0.42 GB per launch).  Per iteration: everything requested has landed (vmcnt(0)) -> barrier ->
+// fp32 weights of this slab -> bf16 terms (registers) -> request the next slab (weights to registers, A terms to the other slot) ->
+// 2 x 2 x NA x NW MFMAs with A fragments from LDS.  No K split, no cross-wave sum; the epilogue is the one of gemm_down_fused, run
+// once per 32-row wave tile.  grid = (ceil(Vpad / 128), 1, Bp / 64), block = 256.
+// 256 x 1500 -> 10000: 105 us (one block per (tile, chunk): 130; chunks per block: 118).  Still 3.7x the MFMA time at peak: what is
+// left is arithmetic on the SIMDs that host two waves -- per wave 54 k cycles of MFMA and ~30 k of splitting fp32 weights into bf16
+// terms, redone by each of the four batch chunks.  Splitting W once per launch (as the chain kernel does) is the open step.
+// ------------------------------------------------------------------------------------------
+template <int NW, int NA>
+__device__ __forceinline__ void down_tiled_body(const float* __restrict__ W, int64_t ldw, int K, int N,
+                                                const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
+                                                const FinishArgs& fa, char* smem) {
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, r = l & 31, hh = l >> 5;
+    const int bx = blockIdx.x, bz = blockIdx.z;
+    const int n0 = bx * 128, mb = bz * 64;
+    const float* wrow = W + (int64_t)min(n0 + 32 * w + r, N - 1) * ldw;
+    const int nblk = lda / 16, nslab = (nblk + 1) / 2;
+    constexpr int SLOT = NA * 4096;                            // NA terms x 2 K16 blocks x (64 rows x 32 B)
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+    // slab s -> slot s & 1: 4 NA instructions of 1 KB, instruction i = ((term * 2 + K16 block) * 2 + row half), dealt to the four waves
+    auto issue_a = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int i = 4 * q + w;
+            const int t = i >> 2, kb2 = (i >> 1) & 1, half = i & 1;
+            const int kb = min(2 * s + kb2, nblk - 1);
+            k3_dma16(A + t * a_term_stride + ((int64_t)kb * fa.Bp + mb + 32 * half) * 16 + 8 * l, ring_lds + (s & 1) * SLOT + i * 1024);
+        }
+    };
+    float wv[16];                                              // this lane's weights of a slab: [K16 block][8 consecutive k]
+    auto load_w = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+            const int k0 = 16 * min(2 * s + kb2, nblk - 1) + 8 * hh;
+            const float4 x0 = *reinterpret_cast<const float4*>(wrow + min(k0, K - 4));
+            const float4 x1 = *reinterpret_cast<const float4*>(wrow + min(k0 + 4, K - 4));
+            wv[8 * kb2 + 0] = x0.x; wv[8 * kb2 + 1] = x0.y; wv[8 * kb2 + 2] = x0.z; wv[8 * kb2 + 3] = x0.w;
+            wv[8 * kb2 + 4] = x1.x; wv[8 * kb2 + 5] = x1.y; wv[8 * kb2 + 6] = x1.z; wv[8 * kb2 + 7] = x1.w;
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    issue_a(0);
+    load_w(0);
+    // (Requesting TWO slabs ahead -- three slots, two register sets, a counted vmcnt -- changed nothing: 110 us against 105 at
+    //  256 x 1500 -> 10000.  Neither the bytes in flight nor the re-read activation terms bound this launch: the SIMDs that host two
+    //  waves (316 blocks on 256 CUs) spend ~84 k cycles per wave, 54 k of MFMA and ~30 k splitting fp32 weights into bf16 terms.)
+    for (int s = 0; s < nslab; ++s) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's share of slab s has landed; its LDS reads of slab s - 1 are done
+        __syncthreads();                                                // ... and so has everybody's: slot s & 1 is complete, the other one is free
+        uint4 bf[2][NW];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = wv[8 * kb2 + j];
+            make_w_frags<NW>(x, bf[kb2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nslab) {                                             // block-uniform
+            issue_a(s + 1);
+            load_w(s + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const char* slot = smem + (s & 1) * SLOT + r * 32 + 16 * hh;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+            if (2 * s + kb2 < nblk) {                                    // block-uniform: an odd number of K16 blocks
+#pragma unroll
+                for (int t = 0; t < NA; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const uint4 af = *reinterpret_cast<const uint4*>(slot + ((t * 2 + kb2) * 2 + mt) * 1024);
+#pragma unroll
+                        for (int tw = 0; tw < NW; ++tw)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(af), as_frag(bf[kb2][tw]), acc[mt], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // epilogue: the ring is free; red = [wave][2][16][64] raw sums, then one 32-row wave tile after the other through `tile`
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    float (*tile)[33] = reinterpret_cast<float (*)[33]>(smem + 32768);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) red[((w * 2 + mt) * 16 + reg) * 64 + l] = acc[mt][reg];
+    __syncthreads();
+    const int c = tid & 31, oct = tid >> 5;
+    const int nt32 = 4 * gridDim.x;                         // 32-row tiles of the launch (= squared-error partials per batch chunk)
+#pragma unroll 1
+    for (int ch = 0; ch < 4; ++ch) {
+        const int ecol = n0 + 32 * ch + c;                  // columns >= N: nothing stored
+        SideIn<8> side;
+        load_side<8>(fa, ecol, mb + oct * 8, side);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cc = (tid >> 6) * 8 + i, mt = cc >> 4, reg = cc & 15;
+            tile[mt * 32 + mfma_row(reg, l)][r] = red[((ch * 2 + mt) * 16 + reg) * 64 + l];
+        }
+        __syncthreads();
+        float xs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xs[i] = tile[oct * 8 + i][c];
+        const float lsum = finish_rows8(fa, ecol, mb + oct * 8, xs, (mb >> 3) + oct, side, RmStage{});
+        __syncthreads();
+        if (fa.loss_part) {
+            const float t = wave_sum(lsum);
+            if (l == 0) tile[0][tid >> 6] = t;
+            __syncthreads();
+            if (tid == 0) fa.loss_part[bz * nt32 + 4 * bx + ch] = ((tile[0][0] + tile[0][1]) + tile[0][2]) + tile[0][3];
+            __syncthreads();
+        }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256, 2) void gemm_down_tiled(const float* __restrict__ W, int64_t ldw, int K, int N,
+                                                          const bf16_t* __restrict__ A, int64_t a_term_stride, int lda,
+                                                          const int* __restrict__ a_flag, int a_terms, const FinishArgs fa) {
+    __shared__ __attribute__((aligned(16))) char smem[32768 + 64 * 33 * 4];      // activation ring (2 x NA x 4 KB), then the epilogue's staging
+    const int na = operand_terms(a_flag, (lda + 63) / 64, fa.Bp / 8, 0, (lda + 63) / 64, a_terms);
+    if (na == 1) down_tiled_body<NW, 1>(W, ldw, K, N, A, a_term_stride, lda, fa, smem);
+    else         down_tiled_body<NW, 3>(W, ldw, K, N, A, a_term_stride, lda, fa, smem);
+}
+
 }  // namespace imdbn

@@ -324,9 +324,10 @@ def test_config4_second_layer_eight_ranks_real_valued_data(_native):
 @pytest.mark.parametrize("V,H,B", [(1041, 132, 128), (4200, 160, 128), (4100, 96, 256), (4100, 200, 256), (4321, 1500, 200),
                                    (10000, 1500, 256), (640, 96, 192)])
 def test_decode_of_a_multi_chunk_batch_one_block_per_weight_tile(_native, V, H, B):
-    """visible_probs / backward (rbm.py:148-151) of more than 64 real-valued rows: one block per 32-row weight tile takes 2 or 4
-    batch chunks (a wave or a wave pair per chunk) instead of one block per (tile, chunk).  Same products, K dealt differently
-    to the waves: equal to the per-chunk launch within fp32 summation order, and to the fp64 value of sigmoid(h W^T + b)."""
+    """visible_probs / backward (rbm.py:148-151) of more than 64 real-valued rows: wide layers take the LDS-tiled kernel (128 weight
+    rows x 64 batch rows per block, activation terms staged once per block); without it one block per 32-row weight tile takes 2 or
+    4 batch chunks; without that, one block per (tile, chunk).  Same products, K dealt differently to the waves: equal within fp32
+    summation order, and to the fp64 value of sigmoid(h W^T + b)."""
     from imdbn.models import RBM
     g = np.random.Generator(np.random.PCG64(V + B))
     W0 = (g.standard_normal((V, H), dtype=F32) / F32(np.sqrt(H))).astype(F32)
@@ -342,6 +343,12 @@ def test_decode_of_a_multi_chunk_batch_one_block_per_weight_tile(_native, V, H, 
         b = r.backward(ht)
     finally:
         _native.set_option("no_down_chunks", 0)
+    _native.set_option("no_down_tiled", 1)                 # (the chunks-per-block form of the per-tile kernel, without the LDS-tiled one)
+    try:
+        b2 = r.backward(ht)
+    finally:
+        _native.set_option("no_down_tiled", 0)
+    assert_close(P.N(a), P.N(b2), 2e-6, "LDS-tiled vs chunks per block", atol=1e-7)
     ref = 1.0 / (1.0 + np.exp(-(h.astype(np.float64) @ W0.astype(np.float64).T + vb.astype(np.float64))))
     assert a.shape == (B, V) and torch.isfinite(a).all()
     assert_close(P.N(a), P.N(b), 2e-6, "chunks in one block vs one block per chunk", atol=1e-7)

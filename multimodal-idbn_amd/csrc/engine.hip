@@ -575,8 +575,8 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         const bool vec4 = (d->ldw % 4 == 0) && (((uintptr_t)d->W & 15) == 0) && (L.H % 4 == 0) && L.H >= 4;
         // several 64-row batch chunks: one block per weight tile takes 2 or 4 of them, a wave (pair) per chunk, on full 32-row
         // tiles (decode / visible_probs of a 256-row batch: 4 x 500 blocks of 20 rows in four rounds -> 313 blocks in one)
-        const int mbb = (mb >= 2 && !abits && !next && vec4 && !(f.rm_src && f.op.rm) && !g_no_down_chunks && L.Vpad >= 128 * 32)
-                            ? (mb % 4 == 0 ? 4 : (mb % 2 == 0 ? 2 : 1)) : 1;      // (fewer than 128 weight tiles: the per-chunk grid fills the chip better)
+        const bool multi = mb >= 2 && !abits && !next && vec4 && !(f.rm_src && f.op.rm) && L.Vpad >= 128 * 32;      // (fewer than 128 weight tiles: the per-chunk grid fills the chip better)
+        const int mbb = (multi && !g_no_down_chunks) ? (mb % 4 == 0 ? 4 : (mb % 2 == 0 ? 2 : 1)) : 1;
         const int down_tr = mbb > 1 ? 32 : L.down_tr;
         dim3 grid(cdiv(L.Vpad, down_tr), 1, mb / mbb);
         c.down_blocks = (int)grid.x;
@@ -585,7 +585,7 @@ int prop(Ctx& c, bool up, OpIn in, FinishArgs f, const PrepArgs* next = nullptr)
         f.op.bits_shape = 1; f.op.bits_cols = down_tr;
         // ... and, where the squared-error partials of 32-row tiles fit, the LDS-tiled kernel: 128 weight rows x 64 batch rows per block,
         // the activation terms staged once per block (kernels_gemm.hpp gemm_down_tiled)
-        if (mbb > 1 && !g_no_down_tiled && (4 * cdiv(L.Vpad, 128) + IMDBN_MAX_GROUPS) * mb <= L.n_loss_slots) {
+        if (multi && !g_no_down_tiled && !g_no_down_chunks && (4 * cdiv(L.Vpad, 128) + IMDBN_MAX_GROUPS) * mb <= L.n_loss_slots) {
             dim3 gt(cdiv(L.Vpad, 128), 1, mb);
             c.down_blocks = 4 * (int)gt.x;
             f.op.bits_cols = 32;

@@ -1316,6 +1316,8 @@ __global__ __launch_bounds__(256, 1) void assoc_update_planes(const AssocPlanesA
 // 256 x 1500 -> 10000: 105 us (one block per (tile, chunk): 130; chunks per block: 118).  Still 3.7x the MFMA time at peak: what is
 // left is arithmetic on the SIMDs that host two waves -- per wave 54 k cycles of MFMA and ~30 k of splitting fp32 weights into bf16
 // terms, redone by each of the four batch chunks.  Splitting W once per launch (as the chain kernel does) is the open step.
+// (Two batch chunks per block -- 128 x 128 tiles, 158 blocks, one wave per SIMD with the accumulators partly in AGPRs -- was built
+//  and was correct, and took 245 us.)
 // ------------------------------------------------------------------------------------------
 template <int NW, int NA>
 __device__ __forceinline__ void down_tiled_body(const float* __restrict__ W, int64_t ldw, int K, int N,

@@ -322,7 +322,7 @@ def test_config4_second_layer_eight_ranks_real_valued_data(_native):
 
 
 @pytest.mark.parametrize("V,H,B", [(1041, 132, 128), (4200, 160, 128), (4100, 96, 256), (4100, 200, 256), (4321, 1500, 200),
-                                   (10000, 1500, 256), (640, 96, 192)])
+                                   (10000, 1500, 256), (640, 96, 192), (4500, 332, 180), (4100, 72, 300)])
 def test_decode_of_a_multi_chunk_batch_one_block_per_weight_tile(_native, V, H, B):
     """visible_probs / backward (rbm.py:148-151) of more than 64 real-valued rows: wide layers take the LDS-tiled kernel (128 weight
     rows x 64 batch rows per block, activation terms staged once per block); without it one block per 32-row weight tile takes 2 or

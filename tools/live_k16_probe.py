@@ -45,6 +45,15 @@ def run(tag):
     print(f"{tag}: default {1e3 * t5:.3f} ms, live K=16 {1e3 * t5k:.3f} ms", flush=True)
     return m
 run("fresh process")
+from imdbn.models import RBM
+jr = RBM(532, 256, 0.04, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=[(500, 532)]).to(dev)
+z = torch.rand(64, 500, device=dev); y = torch.eye(32, device=dev)[torch.randint(0, 32, (64,), device=dev)]
+vp = torch.cat([z, y], 1); vk = torch.zeros(64, 532, device=dev); km = torch.zeros(64, 532, device=dev); vk[:, 500:] = y; km[:, 500:] = 1
+def c3_main():
+    jr.train_epoch(vp, 9, 20, CD=1)
+    jr.train_epoch_clamped(vk, km, 9, 20, CD=1, cond_init_steps=30, sample_h=False, sample_v=False, reclamp_negative=False, aux_lr_mult=0.3, use_noisy_init=True)
+print("C3 main step", 1e3 * timeit(c3_main, 20), "ms")
+run("after the C3 steps")
 X2 = (torch.rand(64 * 32, 10000, device=dev) > 0.9).float()
 dl2 = DataLoader(TensorDataset(X2, torch.zeros(len(X2), 1, device=dev)), batch_size=64, shuffle=False)
 d = iDBN([10000, 1500, 500], dict(params), dl2, dl2, dev)

@@ -46,6 +46,17 @@ def run(tag):
     return m
 run("fresh process")
 from imdbn.models import RBM
+if "--headline" in sys.argv:
+    eng = E.get_hip_engine()
+    rb = RBM(10000, 1500, 0.1, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95).to(dev)
+    bt = [(torch.rand(64, 10000) > 0.9).float().to(dev) for _ in range(16)]
+    E.set_rng(E.PhiloxRng(seed=2, row0=0))
+    if "--profile" in sys.argv: eng.profile(True)
+    for i in range(41): rb.train_epoch(bt[i % 16], 0, 1, CD=1, next_data=bt[(i + 1) % 16])
+    torch.cuda.synchronize()
+    if "--profile" in sys.argv: print("profile_read", eng.profile_read()); eng.profile(False)
+    E.manual_seed(3)
+    run("after the headline steps" + (" with event brackets" if "--profile" in sys.argv else ""))
 jr = RBM(532, 256, 0.04, 1e-4, 0.5, dynamic_lr=True, final_momentum=0.95, softmax_groups=[(500, 532)]).to(dev)
 z = torch.rand(64, 500, device=dev); y = torch.eye(32, device=dev)[torch.randint(0, 32, (64,), device=dev)]
 vp = torch.cat([z, y], 1); vk = torch.zeros(64, 532, device=dev); km = torch.zeros(64, 532, device=dev); vk[:, 500:] = y; km[:, 500:] = 1

@@ -213,14 +213,16 @@ def other_configs(dev):
                                                                                 "iDBN.decode (4 launches)"}}
 
             # iMDBN.train_joint (imdbn.py:540-640): the C3 updates + the per-batch cross-modal metrics, overlapped on a second stream
-            yj = torch.randint(0, 32, (len(X),))
-            dlj = DataLoader(TensorDataset(X.to(dev), torch.eye(32)[yj].to(dev)), batch_size=64, shuffle=False)
+            # (32 batches per epoch, 4 timed epochs: every train_joint call starts with init_joint_bias_from_data over 10 batches and
+            #  ends each epoch with one host read of the metrics -- 20-30 ms per call, which a loop of 32 batches would not amortise)
+            yj = torch.randint(0, 32, (len(X2),))
+            dlj = DataLoader(TensorDataset(X2, torch.eye(32)[yj].to(dev)), batch_size=64, shuffle=False)
             import contextlib, io
             tj = {}
             for ov in (True, False):
                 mj = iMDBN([10000, 1500, 500], 256, params=dict(params, JOINT_METRICS_OVERLAP=ov), dataloader=dlj, val_loader=dlj, device=dev, num_labels=32)
                 with contextlib.redirect_stdout(io.StringIO()):
-                    mj.train_joint(2)
+                    mj.train_joint(1)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     mj.train_joint(4)

@@ -397,7 +397,11 @@ def main():
     # set-up, before the W warm-up steps: one pass over the resident batches (workspace allocation, one-time kernel attributes,
     # first touch of every batch and of both prefetch slots), so that whatever --steps / --warmup the caller picks, no first-time
     # work of any kind sits in the timed region.  The weights it leaves behind are the starting point of the measured run.
-    for i in range(len(batches)):
+    # 16 passes (256 updates, ~26 ms): a device coming out of the build / import idle runs its first ~20 ms of work 3-4 % slower than
+    # its steady state (measured: 20 timed steps after 16 set-up updates 104.9 us per step, after 256 101.0-102.4, after 1024 102.1;
+    # 200 timed steps 98.6-100.8) -- `value` is a throughput, so the timed region starts on a device that is already up.
+    n_prime = int(os.environ.get("IMDBN_BENCH_PRIME", 16 * len(batches)))
+    for i in range(n_prime):
         step(i)
     sync()
     dt, t_enq, stamps, t0, (k3_ms, k3_n), loss = timed_region(not args.no_k3_events and (not use_dp or args.dp_mode == "factors"))
@@ -441,7 +445,7 @@ def main():
                        "arithmetic": "bf16x3 split MFMA (fp32-exact products)" if args.mode == "parity" else "bf16 MFMA",
                        "final_loss": loss, "replicas_identical": ident},
             "global_steps_per_s": args.steps / dt,
-            "setup_steps_before_warmup": len(batches),
+            "setup_steps_before_warmup": n_prime,
             "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
             "host_enqueue_us_p50_max": _p50_max(t0, stamps),
             "frac_hbm_roofline_whole_step": (ups / world) * 16.0 * V * H / (HBM_PEAK_GBS * 1e9),

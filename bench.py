@@ -235,7 +235,12 @@ def other_configs(dev):
                     torch.cuda.synchronize()
                 tj[ov] = (time.perf_counter() - t0) / (4 * len(dlj))
             out["C3_train_joint_loop"] = {"ms_per_batch": 1e3 * tj[True], "ms_per_batch_metrics_inline": 1e3 * tj[False],
-                                          "bound": "dependency latency; the metrics' chains run on a second stream against a snapshot of the joint RBM"}
+                                          "bound": "dependency latency; the metrics' chains run on a second stream against a snapshot of the joint RBM",
+                                          # per batch on the training stream: represent (2 launches) + a CD-1 update + a clamped update with 30 init
+                                          # steps = 66 dependent half steps (C3 main step); the metrics (2 x 50 chain steps + decode) ride beside them
+                                          "roofline": {"bound": "latency", "achieved": 1e6 * tj[True] / 66.0, "peak": None,
+                                                       "unit": "us per dependent half step of the training stream", "frac": None, "traffic": None,
+                                                       "note": "with the metrics in line the batch has 66 + 200 dependent half steps"}}
         finally:
             os.chdir(cwd)
     return out

@@ -71,7 +71,7 @@ __device__ __forceinline__ void store_rm_pc(const OperandOut& o, const uint32_t 
 }
 template <int R>
 __device__ __forceinline__ void store_tr_pc(const OperandOut& o, const uint32_t (&pc)[3][R], int b0, int col, int N, int Bp) {
-    static_assert(R == 8 || R == 2, "rows per thread");
+    static_assert(R == 8 || R == 4 || R == 2, "rows per thread");
     if (o.tr && col < N) {
         bf16_t* q = o.tr + (int64_t)col * Bp + b0;
 #pragma unroll
@@ -82,6 +82,8 @@ __device__ __forceinline__ void store_tr_pc(const OperandOut& o, const uint32_t 
                     *reinterpret_cast<uint4*>(q + t * o.tr_ts) =
                         make_uint4((pc[t][0] | (pc[t][1] << 16)) ^ sg, (pc[t][2] | (pc[t][3] << 16)) ^ sg,
                                    (pc[t][4] | (pc[t][5] << 16)) ^ sg, (pc[t][6] | (pc[t][7] << 16)) ^ sg);
+                else if constexpr (R == 4)
+                    *reinterpret_cast<uint2*>(q + t * o.tr_ts) = make_uint2((pc[t][0] | (pc[t][1] << 16)) ^ sg, (pc[t][2] | (pc[t][3] << 16)) ^ sg);
                 else
                     *reinterpret_cast<uint32_t*>(q + t * o.tr_ts) = (pc[t][0] | (pc[t][1] << 16)) ^ sg;
             }
@@ -379,6 +381,52 @@ __device__ __forceinline__ float finish_lean8(const FinishArgs& a, int col, int 
     }
     if (a.colsum_part && cok) a.colsum_part[(int64_t)part_row * a.N + col] = csum;
     return lsum;
+}
+
+// The same for one column x FOUR rows per thread (k1_stream's last arriver runs its epilogue on all eight waves): the two threads of
+// an 8-row group are lanes l and l + 32 of one wave (rows b0 .. b0 + 3 in the lower half-wave); the four rows are one whole Philox
+// group (row0 % 4 == 0), and the column sum of the 8-row group is lower half + upper half.  No squared error here (K1 has none).
+__device__ __forceinline__ void finish_lean4(const FinishArgs& a, int col, int b0, const float (&xs)[4], int part_row, float bias, int bshape, int bcols) {
+    const bool cok = col < a.N;
+    const int cc = min(col, a.N - 1);
+    const int vmode = a.vmode, colsum_src = a.colsum_src;
+    float us[4];
+    if (vmode != 0) {
+        if (a.uni.tape) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) us[i] = a.uni.tape[(int64_t)min(b0 + i, a.B - 1) * a.uni.N + cc];
+        } else {
+            const uint4 x = draw_block4(a.uni, (uint64_t)(a.uni.row0 + b0), cc);
+            us[0] = u24(x.x); us[1] = u24(x.y); us[2] = u24(x.z); us[3] = u24(x.w);
+        }
+    }
+    float xp[4], xf[4];
+    float csum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool live = cok && (b0 + i) < a.B;
+        const float p = sigmoidf_ref(xs[i] + bias);
+        const float v = vmode == 0 ? p : ((p > us[i]) ? 1.f : 0.f);
+        xp[i] = live ? p : 0.f;
+        xf[i] = live ? v : 0.f;
+        if (live) csum += (colsum_src == 2 ? v : p);
+    }
+    if (a.tr_src) {
+        uint32_t pc[3][4];
+        pieces<4>(a.tr_src == 2 ? xf : xp, a.op.tr_terms, pc);
+        store_tr_pc<4>(a.op, pc, b0, col, a.N, a.Bp);
+    }
+    if (a.op.bits) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_bits_row(a.op, xf[i] != 0.f, col, b0 + i, b0 + i < a.Bp, bshape, bcols);
+    }
+    if (a.out_prob && cok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (b0 + i < a.B) a.out_prob[(int64_t)(b0 + i) * a.ld_prob + col] = xp[i];
+    }
+    const float hi = __shfl_xor(csum, 32, 64);                 // (every lane takes part)
+    if (a.colsum_part && cok && (threadIdx.x & 32) == 0) a.colsum_part[(int64_t)part_row * a.N + col] = csum + hi;
 }
 
 // block = 256 threads = 64 columns x 4 slab-quarters: thread (c, kq) sums slabs k = kq, kq+4, ... of its

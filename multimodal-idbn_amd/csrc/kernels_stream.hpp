@@ -389,7 +389,71 @@ __global__ __launch_bounds__(64 * K1S_WAVES, (RIDER && !GE) ? 4 : 2) void k1_str
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) red[(w * 64 + mt * 32 + mfma_row(reg, l)) * 32 + n] = acc[mt][reg];
     __syncthreads();
-    if (tid >= 256) return;                               // the epilogue is the work of four waves (one column x 8 rows per thread)
+    if constexpr (!GE) {
+        // ---- lean epilogue (the CD configuration): ALL EIGHT waves go on, one column x FOUR rows per thread -- the cross-wave sum, the
+        // publish / combine of the split-K partials and the epilogue are each half as long per thread as with four waves x 8 rows
+        auto sync8 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        const int c = tid & 31, hex = tid >> 5;
+        float xs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (4 * hex + i) * 32 + c;
+            float t = red[o];
+#pragma unroll
+            for (int ww = 1; ww < K1S_WAVES; ++ww) t += red[ww * 2048 + o];
+            xs[i] = t;
+        }
+        int* s_words = reinterpret_cast<int*>(smem + K1S_WAVES * 8192);
+        if (a.amode == K1S_ASSERTED) {                    // promised 0/1 and is not: NaN, loudly (as below)
+            int bad = 0;
+            for (int i = tid; i < wd * 8; i += 64 * K1S_WAVES) bad |= a.aflag[(z * 8 + i / wd) * a.ncb + cb0 + (i % wd)] & FLAG_NONBINARY;
+            const bool wbad = __any(bad) != 0;
+            if (l == 0) s_words[4 + w] = wbad ? 1 : 0;
+            sync8();
+            int anyb = 0;
+#pragma unroll
+            for (int ww = 0; ww < K1S_WAVES; ++ww) anyb |= s_words[4 + ww];
+            if (anyb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xs[i] = __uint_as_float(0x7FC00000u);
+            }
+        }
+        stamp(st, sblk, 3);
+        if (a.ks > 1) {
+            typedef __attribute__((address_space(1))) uint32_t gu32;
+            gu32* mine = (gu32*)(a.slabs + (((int64_t)z * a.ks + sl) * ntiles + tile) * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) __hip_atomic_store(mine + (4 * hex + i) * 32 + c, __float_as_uint(xs[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sync8();                                      // EVERY storing wave drains (vmcnt(0)) before the barrier, the counter add comes after it
+            int* cnt = a.counters + z * ntiles + tile;
+            int* s_last = s_words;
+            if (tid == 0) *s_last = (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ks - 1) ? 1 : 0;
+            sync8();
+            stamp(st, sblk, 4);
+            if (!*s_last) return;
+            if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+            const gu32* s0p = (const gu32*)(a.slabs + ((int64_t)z * a.ks * ntiles + tile) * 2048) + (4 * hex) * 32 + c;
+            for (int k = 0; k < a.ks; k += 8) {           // summed strictly in slice order, as below
+                uint32_t t[8][4];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        t[q][i] = __hip_atomic_load(s0p + (int64_t)min(k + q, a.ks - 1) * ntiles * 2048 + i * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k + q < a.ks) {                       // block-uniform
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xs[i] = (k + q == 0) ? __uint_as_float(t[q][i]) : xs[i] + __uint_as_float(t[q][i]);
+                    }
+            }
+        }
+        stamp(st, sblk, 5);
+        finish_lean4(fa, ecol, mb + 4 * hex, xs, (mb >> 3) + (hex >> 1), sl8.bias, 1, 32);
+        stamp(st, sblk, 6);
+        return;
+    }
+    if (tid >= 256) return;                               // general epilogue: the work of four waves (one column x 8 rows per thread)
     auto sync4 = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };      // the four waves left
     const int c = tid & 31, oct = tid >> 5;
     float xs[8];
